@@ -1,0 +1,156 @@
+/*
+ * detmath.h — deterministic fp64 exp / log for the BP box-plus kernel.
+ *
+ * Why this exists: the reference's box-plus `jacobian()` (src/decoding/decoder.h:12-15)
+ * and its AWGN noise generator (libstdc++ normal_distribution, polar method) call glibc
+ * `exp` / `log`.  glibc's results are not reproducible on a GPU (table driven, FMA usage
+ * selected by ifunc per CPU).  These two routines are pure IEEE-754 binary64 arithmetic
+ * (add, mul, fma, div, integer bit moves) in a fixed evaluation order, so the HIP kernels
+ * and the CPU oracle built with ORC_MATH_DET produce bit-identical results, while staying
+ * within ~1 ulp of the correctly rounded value (and hence of glibc).
+ *
+ * Compile every translation unit that includes this header with -ffp-contract=off:
+ * all fused operations are written explicitly as fma().
+ *
+ * Coefficients come from tools/gen_detmath_coeffs.py (Chebyshev-node fits, errors there).
+ */
+#ifndef LDPC_AMD_DETMATH_H
+#define LDPC_AMD_DETMATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DM_FN __host__ __device__ static inline
+#define DM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#else
+#include <math.h>
+#include <string.h>
+#define DM_FN static inline
+#define DM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#endif
+
+DM_FN uint64_t dm_bits(double x)
+{
+    uint64_t u;
+    __builtin_memcpy(&u, &x, 8);
+    return u;
+}
+
+DM_FN double dm_from_bits(uint64_t u)
+{
+    double x;
+    __builtin_memcpy(&x, &u, 8);
+    return x;
+}
+
+/* exp(r) = 1 + r + r^2 G(r), |r| <= ln2/2, relative error 2^-56.1 */
+#define DM_EXP_G0 0x1.0000000000001p-1
+#define DM_EXP_G1 0x1.5555555555556p-3
+#define DM_EXP_G2 0x1.5555555553d68p-5
+#define DM_EXP_G3 0x1.11111111109b5p-7
+#define DM_EXP_G4 0x1.6c16c17889ef1p-10
+#define DM_EXP_G5 0x1.a01a01a7c2efep-13
+#define DM_EXP_G6 0x1.a019b9149a41cp-16
+#define DM_EXP_G7 0x1.71de0db2f6b19p-19
+#define DM_EXP_G8 0x1.28917c89a43a7p-22
+#define DM_EXP_G9 0x1.af389ecfc4b9cp-26
+
+#define DM_INV_LN2 0x1.71547652b82fep+0
+#define DM_LN2_HI 0x1.62e42fefa39efp-1
+#define DM_LN2_LO 0x1.abc9e3b39803fp-56
+#define DM_RND_MAGIC 0x1.8p52
+
+/*
+ * dm_exp: x = k ln2 + r, exp(x) = 2^k (1 + r + r^2 G(r)).
+ * Finite for x in [-745.2, 709.78]; 0 below, +inf above; NaN propagates.
+ */
+DM_FN double dm_exp(double x)
+{
+    if (!(x == x))
+        return x;
+    if (x > 0x1.62e42fefa39efp+9)
+        return __builtin_huge_val();
+    if (x < -0x1.74910d52d3052p+9)
+        return 0.0;
+    double t = x * DM_INV_LN2;
+    double kd = (t + DM_RND_MAGIC) - DM_RND_MAGIC; /* round to nearest even */
+    double r = DM_FMA(kd, -DM_LN2_HI, x);
+    r = DM_FMA(kd, -DM_LN2_LO, r);
+    double g = DM_EXP_G9;
+    g = DM_FMA(g, r, DM_EXP_G8);
+    g = DM_FMA(g, r, DM_EXP_G7);
+    g = DM_FMA(g, r, DM_EXP_G6);
+    g = DM_FMA(g, r, DM_EXP_G5);
+    g = DM_FMA(g, r, DM_EXP_G4);
+    g = DM_FMA(g, r, DM_EXP_G3);
+    g = DM_FMA(g, r, DM_EXP_G2);
+    g = DM_FMA(g, r, DM_EXP_G1);
+    g = DM_FMA(g, r, DM_EXP_G0);
+    double r2 = r * r;
+    double s = DM_FMA(r2, g, r);
+    double p = 1.0 + s;
+    int64_t k = (int64_t)kd;
+    if (k >= -1021 && k <= 1023)
+        return p * dm_from_bits((uint64_t)(k + 1023) << 52);
+    if (k > 1023) /* k == 1024: p < 1 here, split the scale */
+        return (p * 0x1p1023) * 2.0;
+    /* gradual underflow: two exact power-of-two scalings, one rounding */
+    return (p * dm_from_bits((uint64_t)(k + 1023 + 1000) << 52)) * 0x1p-1000;
+}
+
+/* log(1+f) = f - f^2/2 + s (f^2/2 + z Q(z)), s = f/(2+f), z = s^2, rel. error 2^-57.6 */
+#define DM_LOG_Q0 0x1.5555555555558p-1
+#define DM_LOG_Q1 0x1.99999999952d7p-2
+#define DM_LOG_Q2 0x1.2492492df281ap-2
+#define DM_LOG_Q3 0x1.c71c62e3f11e6p-3
+#define DM_LOG_Q4 0x1.7462b51cb66b1p-3
+#define DM_LOG_Q5 0x1.39fe51a7c18f9p-3
+#define DM_LOG_Q6 0x1.2b5900de53b32p-3
+
+#define DM_LN2_HI32 0x1.62e42fee00000p-1
+#define DM_LN2_LO32 0x1.a39ef35793c76p-33
+#define DM_SQRT_HALF_BITS 0x3FE6A09E667F3BCDull
+
+/*
+ * dm_log: x = 2^k m, m in [sqrt(1/2), sqrt(2)), log x = k ln2 + log(1+f), f = m-1.
+ * x < 0 -> NaN, x == 0 -> -inf, +inf -> +inf, subnormals handled.
+ */
+DM_FN double dm_log(double x)
+{
+    uint64_t ix = dm_bits(x);
+    int64_t kadj = 0;
+    if (ix - 0x0010000000000000ull >= 0x7FE0000000000000ull) /* not positive normal */
+    {
+        if ((ix << 1) == 0)
+            return -__builtin_huge_val();
+        if (ix == 0x7FF0000000000000ull)
+            return x;
+        if ((ix >> 63) || !(x == x))
+            return (x - x) / 0.0 * 0.0 + __builtin_nan("");
+        x = x * 0x1p54; /* subnormal */
+        ix = dm_bits(x);
+        kadj = -54;
+    }
+    uint64_t tmp = ix - DM_SQRT_HALF_BITS;
+    int64_t k = (int64_t)tmp >> 52;
+    double m = dm_from_bits(ix - ((uint64_t)k << 52));
+    k += kadj;
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double q = DM_LOG_Q6;
+    q = DM_FMA(q, z, DM_LOG_Q5);
+    q = DM_FMA(q, z, DM_LOG_Q4);
+    q = DM_FMA(q, z, DM_LOG_Q3);
+    q = DM_FMA(q, z, DM_LOG_Q2);
+    q = DM_FMA(q, z, DM_LOG_Q1);
+    q = DM_FMA(q, z, DM_LOG_Q0);
+    double hfsq = 0.5 * f * f;
+    double t = DM_FMA(z, q, hfsq); /* hfsq + R */
+    double dk = (double)k;
+    double lo = DM_FMA(s, t, dk * DM_LN2_LO32);
+    return DM_FMA(dk, DM_LN2_HI32, f - (hfsq - lo));
+}
+
+#endif /* LDPC_AMD_DETMATH_H */

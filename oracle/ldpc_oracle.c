@@ -1,0 +1,976 @@
+/*
+ * ldpc_oracle.c — CPU oracle (TEST INFRASTRUCTURE ONLY, see ldpc_oracle.h).
+ *
+ * Plain-C restatement of the reference hot path.  Every function cites the reference
+ * file:line it follows (paths relative to heat1q/libldpc).  Third-party arithmetic the
+ * reference pulls in from outside its tree is restated from its published behaviour:
+ *   - libstdc++ 11.4 <random> (bits/random.h, bits/random.tcc): mt19937_64,
+ *     generate_canonical<double,53>, normal_distribution (Marsaglia polar),
+ *     bernoulli_distribution;
+ *   - glibc 2.35 libm exp/log/sqrt/pow (used directly in ORC_MATH_LIBM mode).
+ * Build with -ffp-contract=off (the reference is built for baseline x86-64, no FMA).
+ */
+#define _GNU_SOURCE
+#include "ldpc_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../libldpc_amd/csrc/detmath.h"
+
+/* ------------------------------------------------------------------------------------ */
+/* sparse matrix with file-order adjacency (sparse.h:8-90)                               */
+/* ------------------------------------------------------------------------------------ */
+typedef struct
+{
+    int rows, cols, nnz;
+    int *erow, *ecol;   /* edge list in file order                        */
+    int *rptr, *rnode, *redge; /* per row: neighbour column + edge index, file order */
+    int *cptr, *cnode, *cedge; /* per col: neighbour row + edge index, file order    */
+} spm;
+
+struct orc_code
+{
+    spm H, G;
+    int hasG;
+    int npunct, nshort;
+    int *punct, *shrt;
+    int *bit_pos;
+    int nct, mct, kct, kc, max_degree;
+};
+
+static void spm_free(spm *m)
+{
+    free(m->erow), free(m->ecol);
+    free(m->rptr), free(m->rnode), free(m->redge);
+    free(m->cptr), free(m->cnode), free(m->cedge);
+    memset(m, 0, sizeof *m);
+}
+
+static int line_is_blank(const char *s)
+{
+    for (; *s; ++s)
+        if (*s != ' ' && *s != '\t' && *s != '\r' && *s != '\n')
+            return 0;
+    return 1;
+}
+
+/* sparse.h:92-153: body lines "row col [value]", dims = max index + 1, edge index = line order */
+static int spm_read(spm *m, const char *path, int skip_lines)
+{
+    FILE *fp = fopen(path, "r");
+    if (!fp)
+        return -1;
+    char *line = NULL;
+    size_t cap = 0;
+    int n = 0, capn = 0;
+    int *er = NULL, *ec = NULL;
+    int maxr = 0, maxc = 0;
+    while (skip_lines-- > 0)
+        if (getline(&line, &cap, fp) < 0)
+            break;
+    while (getline(&line, &cap, fp) >= 0)
+    {
+        /* a blank line is undefined behaviour in the reference parser (uninitialised
+           edge); both this oracle and the product skip it */
+        if (line_is_blank(line))
+            continue;
+        int r = 0, c = 0;
+        sscanf(line, "%d %d", &r, &c);
+        if (n == capn)
+        {
+            capn = capn ? capn * 2 : 4096;
+            er = realloc(er, sizeof(int) * capn);
+            ec = realloc(ec, sizeof(int) * capn);
+        }
+        er[n] = r, ec[n] = c;
+        if (r > maxr)
+            maxr = r;
+        if (c > maxc)
+            maxc = c;
+        ++n;
+    }
+    free(line);
+    fclose(fp);
+    m->rows = maxr + 1;
+    m->cols = maxc + 1;
+    m->nnz = n;
+    m->erow = er, m->ecol = ec;
+    m->rptr = calloc(m->rows + 1, sizeof(int));
+    m->cptr = calloc(m->cols + 1, sizeof(int));
+    for (int e = 0; e < n; ++e)
+        m->rptr[er[e] + 1]++, m->cptr[ec[e] + 1]++;
+    for (int i = 0; i < m->rows; ++i)
+        m->rptr[i + 1] += m->rptr[i];
+    for (int j = 0; j < m->cols; ++j)
+        m->cptr[j + 1] += m->cptr[j];
+    m->rnode = malloc(sizeof(int) * (n ? n : 1));
+    m->redge = malloc(sizeof(int) * (n ? n : 1));
+    m->cnode = malloc(sizeof(int) * (n ? n : 1));
+    m->cedge = malloc(sizeof(int) * (n ? n : 1));
+    int *rf = calloc(m->rows, sizeof(int)), *cf = calloc(m->cols, sizeof(int));
+    for (int e = 0; e < n; ++e) /* stable: neighbour lists keep file order */
+    {
+        int r = er[e], c = ec[e];
+        int pr = m->rptr[r] + rf[r]++, pc = m->cptr[c] + cf[c]++;
+        m->rnode[pr] = c, m->redge[pr] = e;
+        m->cnode[pc] = r, m->cedge[pc] = e;
+    }
+    free(rf), free(cf);
+    return 0;
+}
+
+static int contains(const int *a, int n, int v)
+{
+    for (int i = 0; i < n; ++i)
+        if (a[i] == v)
+            return 1;
+    return 0;
+}
+
+/* ldpc.cpp:40-101 */
+orc_code *orc_code_load(const char *pc_file, const char *gen_file)
+{
+    FILE *fp = fopen(pc_file, "r");
+    if (!fp)
+        return NULL;
+    orc_code *c = calloc(1, sizeof *c);
+    char *line = NULL;
+    size_t cap = 0;
+    int skip = 0;
+    while (getline(&line, &cap, fp) >= 0)
+    {
+        char *colon = strchr(line, ':');
+        if (!colon)
+            break;
+        *colon = 0;
+        int is_p = strstr(line, "puncture") != NULL;
+        int is_s = !is_p && strstr(line, "shorten") != NULL;
+        if (is_p || is_s)
+        {
+            char *p = colon + 1, *end;
+            for (;;)
+            {
+                long v = strtol(p, &end, 10);
+                if (end == p)
+                    break;
+                p = end;
+                if (is_p)
+                {
+                    c->punct = realloc(c->punct, sizeof(int) * (c->npunct + 1));
+                    c->punct[c->npunct++] = (int)v;
+                }
+                else
+                {
+                    c->shrt = realloc(c->shrt, sizeof(int) * (c->nshort + 1));
+                    c->shrt[c->nshort++] = (int)v;
+                }
+            }
+        }
+        ++skip;
+    }
+    free(line);
+    fclose(fp);
+    if (spm_read(&c->H, pc_file, skip) != 0)
+    {
+        orc_code_free(c);
+        return NULL;
+    }
+    int md = 0;
+    for (int i = 0; i < c->H.rows; ++i)
+        if (c->H.rptr[i + 1] - c->H.rptr[i] > md)
+            md = c->H.rptr[i + 1] - c->H.rptr[i];
+    for (int j = 0; j < c->H.cols; ++j)
+        if (c->H.cptr[j + 1] - c->H.cptr[j] > md)
+            md = c->H.cptr[j + 1] - c->H.cptr[j];
+    c->max_degree = md;
+    c->bit_pos = malloc(sizeof(int) * c->H.cols);
+    int nb = 0;
+    for (int i = 0; i < c->H.cols; ++i)
+    {
+        if (contains(c->shrt, c->nshort, i) || contains(c->punct, c->npunct, i))
+            continue;
+        c->bit_pos[nb++] = i;
+    }
+    /* ldpc.h:47-59 (note: nct is computed from the list sizes, not from bit_pos) */
+    c->kc = c->H.cols - c->H.rows;
+    c->nct = c->H.cols - c->npunct - c->nshort;
+    c->mct = c->H.rows - c->npunct;
+    c->kct = c->nct - c->mct;
+    if (gen_file && gen_file[0])
+    {
+        if (spm_read(&c->G, gen_file, 0) != 0)
+        {
+            orc_code_free(c);
+            return NULL;
+        }
+        c->hasG = 1;
+    }
+    return c;
+}
+
+void orc_code_free(orc_code *c)
+{
+    if (!c)
+        return;
+    spm_free(&c->H);
+    spm_free(&c->G);
+    free(c->punct), free(c->shrt), free(c->bit_pos);
+    free(c);
+}
+
+int orc_code_nc(const orc_code *c) { return c->H.cols; }
+int orc_code_mc(const orc_code *c) { return c->H.rows; }
+int orc_code_kc(const orc_code *c) { return c->kc; }
+int orc_code_nnz(const orc_code *c) { return c->H.nnz; }
+int orc_code_nct(const orc_code *c) { return c->nct; }
+int orc_code_mct(const orc_code *c) { return c->mct; }
+int orc_code_kct(const orc_code *c) { return c->kct; }
+int orc_code_max_degree(const orc_code *c) { return c->max_degree; }
+int orc_code_num_puncture(const orc_code *c) { return c->npunct; }
+int orc_code_num_shorten(const orc_code *c) { return c->nshort; }
+int orc_code_has_G(const orc_code *c) { return c->hasG; }
+int orc_code_g_rows(const orc_code *c) { return c->hasG ? c->G.rows : 0; }
+int orc_code_g_cols(const orc_code *c) { return c->hasG ? c->G.cols : 0; }
+int orc_code_g_nnz(const orc_code *c) { return c->hasG ? c->G.nnz : 0; }
+void orc_code_edges(const orc_code *c, int *er, int *ec)
+{
+    memcpy(er, c->H.erow, sizeof(int) * c->H.nnz);
+    memcpy(ec, c->H.ecol, sizeof(int) * c->H.nnz);
+}
+void orc_code_bit_pos(const orc_code *c, int *b) { memcpy(b, c->bit_pos, sizeof(int) * c->nct); }
+void orc_code_puncture(const orc_code *c, int *p) { memcpy(p, c->punct, sizeof(int) * c->npunct); }
+void orc_code_shorten(const orc_code *c, int *s) { memcpy(s, c->shrt, sizeof(int) * c->nshort); }
+
+/* sparse.h:201-211: result[i] += right[n] * value over row neighbours (GF(2), result starts 0) */
+void orc_syndrome(const orc_code *c, const uint8_t *word, uint8_t *synd)
+{
+    const spm *H = &c->H;
+    for (int i = 0; i < H->rows; ++i)
+    {
+        uint8_t s = 0;
+        for (int p = H->rptr[i]; p < H->rptr[i + 1]; ++p)
+            s ^= (uint8_t)(word[H->rnode[p]] != 0);
+        synd[i] = s;
+    }
+}
+
+/* sparse.h:163-172: cw[j] += info[row] over column neighbours of G; cw is NOT cleared */
+void orc_encode_accumulate(const orc_code *c, const uint8_t *info, uint8_t *cw)
+{
+    const spm *G = &c->G;
+    for (int j = 0; j < G->cols; ++j)
+        for (int p = G->cptr[j]; p < G->cptr[j + 1]; ++p)
+            cw[j] ^= (uint8_t)(info[G->cnode[p]] != 0);
+}
+
+/* GF(2) rank by dense bitset elimination; the reference's sparse elimination
+   (sparse.h:233-300) computes the same number */
+int orc_rank(const orc_code *c)
+{
+    const spm *H = &c->H;
+    int words = (H->cols + 63) / 64;
+    uint64_t *a = calloc((size_t)H->rows * words, 8);
+    for (int e = 0; e < H->nnz; ++e)
+        a[(size_t)H->erow[e] * words + H->ecol[e] / 64] ^= 1ull << (H->ecol[e] % 64);
+    int rank = 0;
+    for (int col = 0; col < H->cols && rank < H->rows; ++col)
+    {
+        int piv = -1;
+        for (int r = rank; r < H->rows; ++r)
+            if (a[(size_t)r * words + col / 64] >> (col % 64) & 1)
+            {
+                piv = r;
+                break;
+            }
+        if (piv < 0)
+            continue;
+        if (piv != rank)
+            for (int w = 0; w < words; ++w)
+            {
+                uint64_t t = a[(size_t)piv * words + w];
+                a[(size_t)piv * words + w] = a[(size_t)rank * words + w];
+                a[(size_t)rank * words + w] = t;
+            }
+        for (int r = rank + 1; r < H->rows; ++r)
+            if (a[(size_t)r * words + col / 64] >> (col % 64) & 1)
+                for (int w = col / 64; w < words; ++w)
+                    a[(size_t)r * words + w] ^= a[(size_t)rank * words + w];
+        ++rank;
+    }
+    free(a);
+    return rank;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* math dispatch                                                                         */
+/* ------------------------------------------------------------------------------------ */
+double orc_exp(int mode, double x) { return mode == ORC_MATH_DET ? dm_exp(x) : exp(x); }
+double orc_log(int mode, double x) { return mode == ORC_MATH_DET ? dm_log(x) : log(x); }
+
+/* decoder.h:7-10 */
+static inline int sgn(double x) { return 1 - 2 * (int)(signbit(x) != 0); }
+/* std::min(a, b) = (b < a) ? b : a */
+static inline double stdmin(double a, double b) { return (b < a) ? b : a; }
+
+/* decoder.h:12-15 */
+static double jacobian_libm(double x, double y)
+{
+    return sgn(x) * sgn(y) * stdmin(fabs(x), fabs(y)) +
+           log((1 + exp(-fabs(x + y))) / (1 + exp(-fabs(x - y))));
+}
+static double jacobian_det(double x, double y)
+{
+    return sgn(x) * sgn(y) * stdmin(fabs(x), fabs(y)) +
+           dm_log((1 + dm_exp(-fabs(x + y))) / (1 + dm_exp(-fabs(x - y))));
+}
+/* decoder.h:17-20 */
+static double minsum(double x, double y) { return sgn(x) * sgn(y) * stdmin(fabs(x), fabs(y)); }
+
+typedef double (*cn_fn)(double, double);
+
+/* ------------------------------------------------------------------------------------ */
+/* BP decoder state (decoder.h:26-105)                                                   */
+/* ------------------------------------------------------------------------------------ */
+typedef struct
+{
+    const orc_code *code;
+    cn_fn cn;
+    int early_term;
+    unsigned iterations;
+    double *v2c, *c2v, *F, *B, *llr_in, *llr_out;
+    uint8_t *co;
+} dec_t;
+
+static void dec_init(dec_t *d, const orc_code *c, int min_sum, int early_term, unsigned iters, int math)
+{
+    d->code = c;
+    d->cn = min_sum ? minsum : (math == ORC_MATH_DET ? jacobian_det : jacobian_libm);
+    d->early_term = early_term;
+    d->iterations = iters;
+    int nnz = c->H.nnz, nc = c->H.cols, md = c->max_degree > 2 ? c->max_degree : 2;
+    d->v2c = calloc(nnz, 8), d->c2v = calloc(nnz, 8);
+    d->F = calloc(md, 8), d->B = calloc(md, 8);
+    d->llr_in = calloc(nc, 8), d->llr_out = calloc(nc, 8);
+    d->co = calloc(nc, 1);
+}
+static void dec_free(dec_t *d)
+{
+    free(d->v2c), free(d->c2v), free(d->F), free(d->B), free(d->llr_in), free(d->llr_out), free(d->co);
+}
+
+/* decoder.h:47-64 */
+static int is_codeword(const dec_t *d)
+{
+    const spm *H = &d->code->H;
+    for (int i = 0; i < H->rows; ++i)
+    {
+        uint8_t s = 0;
+        for (int p = H->rptr[i]; p < H->rptr[i + 1]; ++p)
+            s ^= d->co[H->rnode[p]];
+        if (s != 0)
+            return 0;
+    }
+    return 1;
+}
+
+/* decoder.cpp:11-78 */
+static int dec_decode(dec_t *d)
+{
+    const spm *H = &d->code->H;
+    for (int e = 0; e < H->nnz; ++e)
+        d->v2c[e] = d->llr_in[H->ecol[e]];
+    unsigned I = 0;
+    while (I < d->iterations)
+    {
+        /* CN pass, decoder.cpp:25-45 */
+        for (int i = 0; i < H->rows; ++i)
+        {
+            int cw = H->rptr[i + 1] - H->rptr[i];
+            const int *cn = H->redge + H->rptr[i];
+            double *F = d->F, *B = d->B;
+            F[0] = d->v2c[cn[0]];
+            B[cw - 1] = d->v2c[cn[cw - 1]];
+            for (int j = 1; j < cw; ++j)
+            {
+                F[j] = d->cn(F[j - 1], d->v2c[cn[j]]);
+                B[cw - 1 - j] = d->cn(B[cw - j], d->v2c[cn[cw - j - 1]]);
+            }
+            d->c2v[cn[0]] = B[1];
+            d->c2v[cn[cw - 1]] = F[cw - 2];
+            for (int j = 1; j < cw - 1; ++j)
+                d->c2v[cn[j]] = d->cn(F[j - 1], B[j + 1]);
+        }
+        /* VN pass + APP + hard decision, decoder.cpp:48-64 */
+        for (int i = 0; i < H->cols; ++i)
+        {
+            double out = d->llr_in[i];
+            for (int p = H->cptr[i]; p < H->cptr[i + 1]; ++p)
+                out += d->c2v[H->cedge[p]];
+            d->llr_out[i] = out;
+            d->co[i] = (uint8_t)(out <= 0);
+            for (int p = H->cptr[i]; p < H->cptr[i + 1]; ++p)
+                d->v2c[H->cedge[p]] = out - d->c2v[H->cedge[p]];
+        }
+        if (d->early_term && is_codeword(d)) /* decoder.cpp:66-72 */
+            break;
+        ++I;
+    }
+    return (int)I;
+}
+
+int orc_decode(const orc_code *c, int min_sum, int early_term, unsigned iterations, int math_mode,
+               const double *llr_in, double *llr_out, uint8_t *hard)
+{
+    dec_t d;
+    dec_init(&d, c, min_sum, early_term, iterations, math_mode);
+    memcpy(d.llr_in, llr_in, 8 * (size_t)c->H.cols);
+    int it = dec_decode(&d);
+    if (llr_out)
+        memcpy(llr_out, d.llr_out, 8 * (size_t)c->H.cols);
+    if (hard)
+        memcpy(hard, d.co, c->H.cols);
+    dec_free(&d);
+    return it;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* BEC decoder (decoder.h:130-156, decoder.cpp:91-192)                                   */
+/* ------------------------------------------------------------------------------------ */
+typedef struct
+{
+    const orc_code *code;
+    int early_term, deg1_compat;
+    unsigned iterations;
+    uint8_t *v2c, *c2v, *F, *B, *llr_in, *llr_out, *co;
+} becdec_t;
+
+static inline uint8_t bec_vn(uint8_t l, uint8_t r, uint8_t xi) /* decoder.h:145-148 */
+{
+    return (xi == l || xi == r) ? xi : ORC_ERASURE;
+}
+static inline uint8_t bec_cn(uint8_t l, uint8_t r) /* decoder.h:152-155 */
+{
+    return (l == ORC_ERASURE || r == ORC_ERASURE) ? ORC_ERASURE : (uint8_t)((l != 0) ^ (r != 0));
+}
+
+static void becdec_init(becdec_t *d, const orc_code *c, int early_term, unsigned iters, int compat)
+{
+    d->code = c, d->early_term = early_term, d->iterations = iters, d->deg1_compat = compat;
+    int nnz = c->H.nnz, nc = c->H.cols, md = c->max_degree > 2 ? c->max_degree : 2;
+    d->v2c = calloc(nnz, 1), d->c2v = calloc(nnz, 1);
+    d->F = calloc(md, 1), d->B = calloc(md, 1);
+    d->llr_in = calloc(nc, 1), d->llr_out = calloc(nc, 1), d->co = calloc(nc, 1);
+}
+static void becdec_free(becdec_t *d)
+{
+    free(d->v2c), free(d->c2v), free(d->F), free(d->B), free(d->llr_in), free(d->llr_out), free(d->co);
+}
+
+static int becdec_decode(becdec_t *d, const uint8_t *x /* true codeword, gf2 values */)
+{
+    const spm *H = &d->code->H;
+    for (int e = 0; e < H->nnz; ++e)
+        d->v2c[e] = d->llr_in[H->ecol[e]];
+    unsigned I = 0;
+    while (I < d->iterations)
+    {
+        for (int i = 0; i < H->rows; ++i) /* decoder.cpp:105-123 */
+        {
+            int cw = H->rptr[i + 1] - H->rptr[i];
+            const int *cn = H->redge + H->rptr[i];
+            uint8_t *F = d->F, *B = d->B;
+            F[0] = d->v2c[cn[0]];
+            B[cw - 1] = d->v2c[cn[cw - 1]];
+            for (int j = 1; j < cw; ++j)
+            {
+                F[j] = bec_cn(F[j - 1], d->v2c[cn[j]]);
+                B[cw - 1 - j] = bec_cn(B[cw - j], d->v2c[cn[cw - j - 1]]);
+            }
+            d->c2v[cn[0]] = B[1];
+            d->c2v[cn[cw - 1]] = F[cw - 2];
+            for (int j = 1; j < cw - 1; ++j)
+                d->c2v[cn[j]] = bec_cn(F[j - 1], B[j + 1]);
+        }
+        for (int i = 0; i < H->cols; ++i) /* decoder.cpp:126-167 */
+        {
+            int vw = H->cptr[i + 1] - H->cptr[i];
+            const int *vn = H->cedge + H->cptr[i];
+            if (d->llr_in[i] != ORC_ERASURE)
+            {
+                for (int p = 0; p < vw; ++p)
+                    d->v2c[vn[p]] = x[i];
+                d->llr_out[i] = x[i];
+                d->co[i] = x[i];
+            }
+            else
+            {
+                uint8_t *F = d->F, *B = d->B;
+                if (vw == 1)
+                {
+                    /* The reference reads mExMsgF[-1] here (decoder.cpp:155-156).
+                       deg1_compat reproduces what that read returns with glibc malloc (0);
+                       otherwise the defined extrinsic of a degree-1 erased VN: an erasure. */
+                    F[0] = d->c2v[vn[0]];
+                    d->v2c[vn[0]] = d->deg1_compat ? 0 : ORC_ERASURE;
+                    d->llr_out[i] = F[0];
+                }
+                else
+                {
+                    F[0] = d->c2v[vn[0]];
+                    B[vw - 1] = d->c2v[vn[vw - 1]];
+                    for (int j = 1; j < vw; ++j)
+                    {
+                        F[j] = bec_vn(F[j - 1], d->c2v[vn[j]], x[i]);
+                        B[vw - 1 - j] = bec_vn(B[vw - j], d->c2v[vn[vw - j - 1]], x[i]);
+                    }
+                    d->v2c[vn[0]] = B[1];
+                    d->v2c[vn[vw - 1]] = F[vw - 2];
+                    for (int j = 1; j < vw - 1; ++j)
+                        d->v2c[vn[j]] = bec_vn(F[j - 1], B[j + 1], x[i]);
+                    d->llr_out[i] = F[vw - 1];
+                }
+                /* -gf2 is always 1 (gf2.cpp:5-8) */
+                d->co[i] = (d->llr_out[i] == ORC_ERASURE) ? 1 : x[i];
+            }
+        }
+        if (d->early_term) /* decoder.cpp:169-186 */
+        {
+            int found = 0;
+            for (int i = 0; i < H->cols; ++i)
+                if (d->llr_out[i] == ORC_ERASURE)
+                {
+                    found = 1;
+                    break;
+                }
+            if (!found)
+                break;
+        }
+        ++I;
+    }
+    return (int)I;
+}
+
+int orc_decode_bec(const orc_code *c, int early_term, unsigned iterations, int deg1_compat,
+                   const uint8_t *llr_in, const uint8_t *codeword, uint8_t *llr_out, uint8_t *hard)
+{
+    becdec_t d;
+    becdec_init(&d, c, early_term, iterations, deg1_compat);
+    memcpy(d.llr_in, llr_in, c->H.cols);
+    int it = becdec_decode(&d, codeword);
+    if (llr_out)
+        memcpy(llr_out, d.llr_out, c->H.cols);
+    if (hard)
+        memcpy(hard, d.co, c->H.cols);
+    becdec_free(&d);
+    return it;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* libstdc++ <random> restated                                                           */
+/* ------------------------------------------------------------------------------------ */
+#define MT_N 312
+#define MT_M 156
+typedef struct
+{
+    uint64_t x[MT_N];
+    int p;
+    uint64_t draws;
+} mt64;
+
+static void mt64_seed(mt64 *g, uint64_t seed)
+{
+    g->x[0] = seed;
+    for (int i = 1; i < MT_N; ++i)
+        g->x[i] = 6364136223846793005ull * (g->x[i - 1] ^ (g->x[i - 1] >> 62)) + (uint64_t)i;
+    g->p = MT_N;
+    g->draws = 0;
+}
+
+static uint64_t mt64_next(mt64 *g)
+{
+    if (g->p >= MT_N)
+    {
+        const uint64_t UM = 0xFFFFFFFF80000000ull, LM = 0x7FFFFFFFull, A = 0xB5026F5AA96619E9ull;
+        for (int k = 0; k < MT_N; ++k)
+        {
+            uint64_t y = (g->x[k] & UM) | (g->x[(k + 1) % MT_N] & LM);
+            g->x[k] = g->x[(k + MT_M) % MT_N] ^ (y >> 1) ^ ((y & 1) ? A : 0);
+        }
+        g->p = 0;
+    }
+    uint64_t z = g->x[g->p++];
+    z ^= (z >> 29) & 0x5555555555555555ull;
+    z ^= (z << 17) & 0x71D67FFFEDA60000ull;
+    z ^= (z << 37) & 0xFFF7EEE000000000ull;
+    z ^= (z >> 43);
+    g->draws++;
+    return z;
+}
+
+void orc_mt64_stream(uint64_t seed, uint64_t n, uint64_t *out)
+{
+    mt64 g;
+    mt64_seed(&g, seed);
+    for (uint64_t i = 0; i < n; ++i)
+        out[i] = mt64_next(&g);
+}
+
+/* generate_canonical<double,53>: one draw, u64 -> double (round to nearest) / 2^64 */
+static double canonical(mt64 *g)
+{
+    double r = (double)mt64_next(g) / 18446744073709551616.0;
+    if (r >= 1.0)
+        r = nextafter(1.0, 0.0);
+    return r;
+}
+
+typedef struct
+{
+    double stddev;
+    double saved;
+    int saved_ok;
+} normal_t;
+
+/* normal_distribution::operator() (random.tcc): polar method, returns y*mult first */
+static double normal_draw(normal_t *n, mt64 *g, int math)
+{
+    double ret;
+    if (n->saved_ok)
+    {
+        n->saved_ok = 0;
+        ret = n->saved;
+    }
+    else
+    {
+        double x, y, r2;
+        do
+        {
+            x = 2.0 * canonical(g) - 1.0;
+            y = 2.0 * canonical(g) - 1.0;
+            r2 = x * x + y * y;
+        } while (r2 > 1.0 || r2 == 0.0);
+        double mult = sqrt(-2 * orc_log(math, r2) / r2);
+        n->saved = x * mult;
+        n->saved_ok = 1;
+        ret = y * mult;
+    }
+    return ret * n->stddev + 0.0;
+}
+
+static int bernoulli_draw(mt64 *g, double p) { return canonical(g) < p; }
+
+/* ------------------------------------------------------------------------------------ */
+/* channels (channel.h, channel.cpp)                                                     */
+/* ------------------------------------------------------------------------------------ */
+struct orc_chan
+{
+    const orc_code *code;
+    int type, math;
+    mt64 seed_state; /* mRNG: never advances (channel.cpp:37-42 binds a COPY)            */
+    mt64 noise;      /* the bound copy that actually produces the noise                  */
+    mt64 info;       /* mt19937_64(seed << 1), persists across channel points            */
+    normal_t nrm;
+    double param, sigma2;
+    uint8_t *info_word, *cw; /* kc, nc                                                   */
+    double *xd, *yd;         /* AWGN channel i/o (nct)                                   */
+    uint8_t *xb, *yb;        /* BSC/BEC channel i/o (nct)                                */
+    dec_t dec;
+    becdec_t bdec;
+    double *bec_llr_in_d, *bec_llr_out_d;
+};
+
+orc_chan *orc_chan_new(const orc_code *c, int type, uint64_t seed, int math, int min_sum,
+                       int early_term, unsigned iterations, int bec_compat)
+{
+    orc_chan *ch = calloc(1, sizeof *ch);
+    ch->code = c, ch->type = type, ch->math = math;
+    mt64_seed(&ch->seed_state, seed);
+    ch->noise = ch->seed_state;
+    mt64_seed(&ch->info, seed << 1); /* channel.cpp:11 */
+    int nct = c->nct, nc = c->H.cols;
+    ch->info_word = calloc(c->kc > 0 ? c->kc : 1, 1);
+    ch->cw = calloc(nc, 1);
+    ch->xd = malloc(8 * (size_t)nct), ch->yd = calloc(nct, 8);
+    for (int i = 0; i < nct; ++i)
+        ch->xd[i] = 1.0; /* all-zero codeword, channel.cpp:28 */
+    ch->xb = calloc(nct, 1), ch->yb = calloc(nct, 1);
+    if (type == ORC_BEC)
+        becdec_init(&ch->bdec, c, early_term, iterations, bec_compat);
+    else
+        dec_init(&ch->dec, c, min_sum, early_term, iterations, math);
+    /* constructor defaults (ldpcsim.cpp:39,52,65): snr 1.0 / eps 0.0; start() always
+       calls set_channel_param before the first frame */
+    orc_chan_set_param(ch, type == ORC_AWGN ? 1.0 : 0.0);
+    return ch;
+}
+
+void orc_chan_free(orc_chan *ch)
+{
+    if (!ch)
+        return;
+    free(ch->info_word), free(ch->cw), free(ch->xd), free(ch->yd), free(ch->xb), free(ch->yb);
+    if (ch->type == ORC_BEC)
+        becdec_free(&ch->bdec);
+    else
+        dec_free(&ch->dec);
+    free(ch->bec_llr_in_d), free(ch->bec_llr_out_d);
+    free(ch);
+}
+
+void orc_chan_set_param(orc_chan *ch, double x)
+{
+    ch->param = x;
+    ch->noise = ch->seed_state; /* std::bind copies mRNG: the stream restarts */
+    ch->noise.draws = 0;
+    if (ch->type == ORC_AWGN)
+    {
+        ch->sigma2 = pow(10, -x / 10);
+        ch->nrm.stddev = sqrt(ch->sigma2);
+        ch->nrm.saved_ok = 0;
+    }
+}
+
+void orc_chan_encode_and_map(orc_chan *ch)
+{
+    const orc_code *c = ch->code;
+    for (int i = 0; i < c->kc; ++i)
+        ch->info_word[i] = (uint8_t)bernoulli_draw(&ch->info, 0.5);
+    orc_encode_accumulate(c, ch->info_word, ch->cw);
+    for (int i = 0; i < c->nct; ++i)
+    {
+        uint8_t b = ch->cw[c->bit_pos[i]];
+        if (ch->type == ORC_AWGN)
+            ch->xd[i] = 1 - (2 * b);
+        else
+            ch->xb[i] = b;
+    }
+}
+
+void orc_chan_simulate(orc_chan *ch)
+{
+    int nct = ch->code->nct;
+    if (ch->type == ORC_AWGN)
+        for (int i = 0; i < nct; ++i)
+            ch->yd[i] = normal_draw(&ch->nrm, &ch->noise, ch->math) + ch->xd[i];
+    else if (ch->type == ORC_BSC)
+        for (int i = 0; i < nct; ++i)
+            ch->yb[i] = ch->xb[i] ^ (uint8_t)bernoulli_draw(&ch->noise, ch->param);
+    else
+        for (int i = 0; i < nct; ++i)
+            ch->yb[i] = bernoulli_draw(&ch->noise, ch->param) ? ORC_ERASURE : ch->xb[i];
+}
+
+void orc_chan_calc_llrs(orc_chan *ch)
+{
+    const orc_code *c = ch->code;
+    if (ch->type == ORC_AWGN)
+    {
+        double *L = ch->dec.llr_in;
+        for (int i = 0; i < c->npunct; ++i)
+            L[c->punct[i]] = 0.0;
+        for (int i = 0; i < c->nshort; ++i)
+            L[c->shrt[i]] = 99999.9;
+        for (int i = 0; i < c->nct; ++i)
+            L[c->bit_pos[i]] = 2 * ch->yd[i] / ch->sigma2;
+    }
+    else if (ch->type == ORC_BSC)
+    {
+        double *L = ch->dec.llr_in;
+        const double delta = log((1 - ch->param) / ch->param);
+        for (int i = 0; i < c->npunct; ++i)
+            L[c->punct[i]] = 0.0;
+        for (int i = 0; i < c->nshort; ++i)
+            L[c->shrt[i]] = delta;
+        for (int i = 0; i < c->nct; ++i)
+            L[c->bit_pos[i]] = delta * (1 - 2 * (int)ch->yb[i]);
+    }
+    else
+    {
+        uint8_t *L = ch->bdec.llr_in;
+        for (int i = 0; i < c->npunct; ++i)
+            L[c->punct[i]] = ORC_ERASURE;
+        for (int i = 0; i < c->nshort; ++i) /* channel.cpp:222: indexes mX by column index */
+            L[c->shrt[i]] = c->shrt[i] < c->nct ? ch->xb[c->shrt[i]] : 0;
+        for (int i = 0; i < c->nct; ++i)
+            L[c->bit_pos[i]] = ch->yb[i];
+    }
+}
+
+int orc_chan_decode(orc_chan *ch)
+{
+    return ch->type == ORC_BEC ? becdec_decode(&ch->bdec, ch->cw) : dec_decode(&ch->dec);
+}
+
+const double *orc_chan_llr_in(const orc_chan *ch) { return ch->dec.llr_in; }
+const double *orc_chan_llr_out(const orc_chan *ch) { return ch->dec.llr_out; }
+const uint8_t *orc_chan_llr_in_bec(const orc_chan *ch) { return ch->bdec.llr_in; }
+const uint8_t *orc_chan_llr_out_bec(const orc_chan *ch) { return ch->bdec.llr_out; }
+const uint8_t *orc_chan_estimate(const orc_chan *ch)
+{
+    return ch->type == ORC_BEC ? ch->bdec.co : ch->dec.co;
+}
+const uint8_t *orc_chan_codeword(const orc_chan *ch) { return ch->cw; }
+uint64_t orc_chan_raw_draws(const orc_chan *ch) { return ch->noise.draws; }
+
+static uint32_t count_bit_errors(const orc_chan *ch) /* ldpcsim.cpp:184-188 */
+{
+    const orc_code *c = ch->code;
+    const uint8_t *est = orc_chan_estimate(ch);
+    uint32_t n = 0;
+    for (int i = 0; i < c->nct; ++i)
+        n += est[c->bit_pos[i]] != ch->cw[c->bit_pos[i]];
+    return n;
+}
+
+void orc_chan_run_frames(orc_chan *ch, uint64_t skip, uint64_t count, uint32_t *iters,
+                         uint32_t *bit_errors, uint8_t *hard, double *llr_in, double *llr_out,
+                         uint8_t *codeword)
+{
+    const orc_code *c = ch->code;
+    size_t nc = (size_t)c->H.cols;
+    for (uint64_t f = 0; f < skip + count; ++f)
+    {
+        if (c->hasG)
+            orc_chan_encode_and_map(ch);
+        orc_chan_simulate(ch);
+        if (f < skip)
+            continue;
+        orc_chan_calc_llrs(ch);
+        uint64_t k = f - skip;
+        if (llr_in)
+            for (size_t i = 0; i < nc; ++i)
+                llr_in[k * nc + i] = ch->type == ORC_BEC ? (double)ch->bdec.llr_in[i] : ch->dec.llr_in[i];
+        int it = orc_chan_decode(ch);
+        if (iters)
+            iters[k] = (uint32_t)it;
+        if (bit_errors)
+            bit_errors[k] = count_bit_errors(ch);
+        if (hard)
+            memcpy(hard + k * nc, orc_chan_estimate(ch), nc);
+        if (llr_out)
+            for (size_t i = 0; i < nc; ++i)
+                llr_out[k * nc + i] = ch->type == ORC_BEC ? (double)ch->bdec.llr_out[i] : ch->dec.llr_out[i];
+        if (codeword)
+            memcpy(codeword + k * nc, ch->cw, nc);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* simulation loop (ldpcsim.cpp:97-263)                                                  */
+/* ------------------------------------------------------------------------------------ */
+static double now_us(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
+int orc_simulate(const orc_code *c, int chan_type, uint64_t seed, const double xr[3], int min_sum,
+                 int early_term, unsigned iterations, int math, int bec_compat, unsigned threads,
+                 uint64_t max_frames, uint64_t min_fec, orc_results *res, uint64_t *totals,
+                 const volatile uint8_t *stop_flag)
+{
+    /* x values: ldpcsim.cpp:104-122 */
+    int nx = 0, capx = 0;
+    double *xv = NULL;
+    double val = xr[0];
+    while (val < xr[1])
+    {
+        if (nx == capx)
+            xv = realloc(xv, 8 * (size_t)(capx = capx ? capx * 2 : 64));
+        xv[nx++] = val;
+        val += xr[2];
+    }
+    if (chan_type == ORC_BSC || chan_type == ORC_BEC)
+        for (int i = 0; i < nx / 2; ++i)
+        {
+            double t = xv[i];
+            xv[i] = xv[nx - 1 - i];
+            xv[nx - 1 - i] = t;
+        }
+    if (threads < 1)
+        threads = 1;
+    orc_chan **chs = calloc(threads, sizeof *chs);
+    for (unsigned t = 0; t < threads; ++t) /* ldpcsim.cpp:29-75: seed + i */
+        chs[t] = orc_chan_new(c, chan_type, seed + t, math, min_sum, early_term, iterations, bec_compat);
+    static const volatile uint8_t never = 0;
+    if (!stop_flag)
+        stop_flag = &never;
+    const uint64_t nc = (uint64_t)c->H.cols;
+
+    for (int i = 0; i < nx; ++i)
+    {
+        uint64_t bec = 0, fec = 0, frames = 0, iters = 0;
+        double t_start = now_us();
+#pragma omp parallel num_threads(threads) shared(bec, fec, frames, iters, t_start)
+        {
+#ifdef _OPENMP
+            unsigned tid = (unsigned)omp_get_thread_num();
+#else
+            unsigned tid = 0;
+#endif
+            orc_chan *ch = chs[tid];
+            orc_chan_set_param(ch, xv[i]);
+            uint64_t fec_seen, frames_seen;
+            do
+            {
+                if (c->hasG)
+                    orc_chan_encode_and_map(ch);
+                orc_chan_simulate(ch);
+                orc_chan_calc_llrs(ch);
+                uint64_t it = (uint64_t)orc_chan_decode(ch);
+#pragma omp atomic update
+                iters += it;
+#pragma omp atomic read
+                fec_seen = fec;
+                if (fec_seen < min_fec)
+                {
+                    uint64_t fr;
+#pragma omp atomic capture
+                    fr = ++frames;
+                    uint32_t bt = count_bit_errors(ch);
+                    if (bt > 0)
+                    {
+                        double t_now = now_us();
+                        uint64_t t_frame = (uint64_t)(t_now - t_start) / fr;
+#pragma omp critical
+                        {
+                            bec += bt;
+                            ++fec;
+                            if (res)
+                            {
+                                res->fer[i] = (double)fec / frames;
+                                res->ber[i] = (double)bec / (frames * nc);
+                                res->avg_iter[i] = (double)iters / frames;
+                                res->time[i] = (double)t_frame * 1e-6;
+                                res->fec[i] = fec;
+                                res->frames[i] = frames;
+                            }
+                        }
+                    }
+                }
+#pragma omp atomic read
+                fec_seen = fec;
+#pragma omp atomic read
+                frames_seen = frames;
+            } while (fec_seen < min_fec && frames_seen < max_frames && !*stop_flag);
+        }
+        if (totals)
+        {
+            totals[4 * i + 0] = frames, totals[4 * i + 1] = fec;
+            totals[4 * i + 2] = bec, totals[4 * i + 3] = iters;
+        }
+    }
+    for (unsigned t = 0; t < threads; ++t)
+        orc_chan_free(chs[t]);
+    free(chs);
+    free(xv);
+    return nx;
+}

@@ -1,0 +1,198 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) — test infrastructure only.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as ct
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+H_TXT = os.path.join(GOLDEN, "h.txt")
+G_TXT = os.path.join(GOLDEN, "g.txt")
+
+MATH_LIBM, MATH_DET = 0, 1
+AWGN, BSC, BEC = 1, 2, 3
+CHAN = {"AWGN": AWGN, "BSC": BSC, "BEC": BEC}
+ERASURE = ord("E")
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, os.path.join(ORACLE_DIR, "liboracle.so")])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    src = os.path.join(ORACLE_DIR, "ldpc_oracle.c")
+    if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        build()
+    L = ct.CDLL(LIB_PATH)
+    vp, i32, u32, u64, dbl = ct.c_void_p, ct.c_int, ct.c_uint, ct.c_uint64, ct.c_double
+    L.orc_code_load.restype = vp
+    L.orc_code_load.argtypes = [ct.c_char_p, ct.c_char_p]
+    L.orc_code_free.argtypes = [vp]
+    for name in ("nc", "mc", "kc", "nnz", "nct", "mct", "kct", "max_degree", "num_puncture",
+                 "num_shorten", "has_G", "g_rows", "g_cols", "g_nnz"):
+        f = getattr(L, "orc_code_" + name)
+        f.restype, f.argtypes = i32, [vp]
+    L.orc_code_edges.argtypes = [vp, vp, vp]
+    for name in ("bit_pos", "puncture", "shorten"):
+        getattr(L, "orc_code_" + name).argtypes = [vp, vp]
+    L.orc_syndrome.argtypes = [vp, vp, vp]
+    L.orc_encode_accumulate.argtypes = [vp, vp, vp]
+    L.orc_rank.restype, L.orc_rank.argtypes = i32, [vp]
+    L.orc_decode.restype = i32
+    L.orc_decode.argtypes = [vp, i32, i32, u32, i32, vp, vp, vp]
+    L.orc_decode_bec.restype = i32
+    L.orc_decode_bec.argtypes = [vp, i32, u32, i32, vp, vp, vp, vp]
+    L.orc_chan_new.restype = vp
+    L.orc_chan_new.argtypes = [vp, i32, u64, i32, i32, i32, u32, i32]
+    L.orc_chan_free.argtypes = [vp]
+    L.orc_chan_set_param.argtypes = [vp, dbl]
+    L.orc_chan_raw_draws.restype, L.orc_chan_raw_draws.argtypes = u64, [vp]
+    L.orc_chan_run_frames.argtypes = [vp, u64, u64, vp, vp, vp, vp, vp, vp]
+    L.orc_simulate.restype = i32
+    L.orc_simulate.argtypes = [vp, i32, u64, vp, i32, i32, u32, i32, i32, u32, u64, u64, vp, vp, vp]
+    L.orc_mt64_stream.argtypes = [u64, u64, vp]
+    L.orc_exp.restype, L.orc_exp.argtypes = dbl, [i32, dbl]
+    L.orc_log.restype, L.orc_log.argtypes = dbl, [i32, dbl]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ct.c_void_p)
+
+
+class Results(ct.Structure):
+    _fields_ = [("fer", ct.c_void_p), ("ber", ct.c_void_p), ("avg_iter", ct.c_void_p),
+                ("time", ct.c_void_p), ("fec", ct.c_void_p), ("frames", ct.c_void_p)]
+
+
+class Code:
+    def __init__(self, pc_file, gen_file=""):
+        L = lib()
+        self.h = L.orc_code_load(pc_file.encode(), gen_file.encode())
+        if not self.h:
+            raise OSError("oracle: cannot open " + pc_file)
+        for name in ("nc", "mc", "kc", "nnz", "nct", "mct", "kct", "max_degree", "num_puncture",
+                     "num_shorten", "has_G", "g_rows", "g_cols", "g_nnz"):
+            setattr(self, name, getattr(L, "orc_code_" + name)(self.h))
+        self.edge_row = np.zeros(self.nnz, np.int32)
+        self.edge_col = np.zeros(self.nnz, np.int32)
+        L.orc_code_edges(self.h, _p(self.edge_row), _p(self.edge_col))
+        self.bit_pos = np.zeros(self.nct, np.int32)
+        L.orc_code_bit_pos(self.h, _p(self.bit_pos))
+        self.puncture = np.zeros(self.num_puncture, np.int32)
+        L.orc_code_puncture(self.h, _p(self.puncture))
+        self.shorten = np.zeros(self.num_shorten, np.int32)
+        L.orc_code_shorten(self.h, _p(self.shorten))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_code_free(self.h)
+            self.h = None
+
+    def rank(self):
+        return lib().orc_rank(self.h)
+
+    def syndrome(self, word):
+        word = np.ascontiguousarray(word, np.uint8)
+        s = np.zeros(self.mc, np.uint8)
+        lib().orc_syndrome(self.h, _p(word), _p(s))
+        return s
+
+    def encode(self, info):
+        """u*G on all nc columns (fresh codeword)."""
+        info = np.ascontiguousarray(info, np.uint8)
+        cw = np.zeros(self.g_cols, np.uint8)
+        lib().orc_encode_accumulate(self.h, _p(info), _p(cw))
+        return cw
+
+    def decode(self, llr_in, min_sum=False, early_term=True, iters=50, math=MATH_LIBM):
+        llr_in = np.ascontiguousarray(llr_in, np.float64)
+        assert llr_in.shape == (self.nc,)
+        out = np.zeros(self.nc, np.float64)
+        hard = np.zeros(self.nc, np.uint8)
+        it = lib().orc_decode(self.h, int(min_sum), int(early_term), iters, math, _p(llr_in), _p(out), _p(hard))
+        return it, out, hard
+
+    def decode_bec(self, llr_in, codeword, early_term=True, iters=50, compat=False):
+        llr_in = np.ascontiguousarray(llr_in, np.uint8)
+        codeword = np.ascontiguousarray(codeword, np.uint8)
+        out = np.zeros(self.nc, np.uint8)
+        hard = np.zeros(self.nc, np.uint8)
+        it = lib().orc_decode_bec(self.h, int(early_term), iters, int(compat), _p(llr_in), _p(codeword), _p(out), _p(hard))
+        return it, out, hard
+
+    def run_frames(self, chan, x, seed=0, skip=0, count=1, min_sum=False, early_term=True, iters=50,
+                   math=MATH_LIBM, bec_compat=False, want_vectors=True):
+        """Frames [skip, skip+count) of stream mt19937_64(seed) at channel point x."""
+        L = lib()
+        ch = L.orc_chan_new(self.h, CHAN[chan] if isinstance(chan, str) else chan, seed, math,
+                            int(min_sum), int(early_term), iters, int(bec_compat))
+        L.orc_chan_set_param(ch, float(x))
+        r = {"iters": np.zeros(count, np.uint32), "bit_errors": np.zeros(count, np.uint32)}
+        if want_vectors:
+            r["hard"] = np.zeros((count, self.nc), np.uint8)
+            r["llr_in"] = np.zeros((count, self.nc), np.float64)
+            r["llr_out"] = np.zeros((count, self.nc), np.float64)
+            r["codeword"] = np.zeros((count, self.nc), np.uint8)
+        L.orc_chan_run_frames(ch, skip, count, _p(r["iters"]), _p(r["bit_errors"]), _p(r.get("hard")),
+                              _p(r.get("llr_in")), _p(r.get("llr_out")), _p(r.get("codeword")))
+        r["raw_draws"] = L.orc_chan_raw_draws(ch)
+        L.orc_chan_free(ch)
+        return r
+
+    def simulate(self, chan, x_range, seed=0, min_sum=False, early_term=True, iters=50, math=MATH_LIBM,
+                 bec_compat=False, threads=1, max_frames=10**10, min_fec=50):
+        L = lib()
+        xr = np.asarray(x_range, np.float64)
+        n_max = max(1, int(np.ceil((xr[1] - xr[0]) / xr[2])) + 2)
+        arrs = {k: np.zeros(n_max, np.float64) for k in ("fer", "ber", "avg_iter", "time")}
+        arrs["fec"] = np.zeros(n_max, np.uint64)
+        arrs["frames"] = np.zeros(n_max, np.uint64)
+        res = Results(*[arrs[k].ctypes.data for k in ("fer", "ber", "avg_iter", "time", "fec", "frames")])
+        totals = np.zeros(4 * n_max, np.uint64)
+        nx = L.orc_simulate(self.h, CHAN[chan], seed, _p(xr), int(min_sum), int(early_term), iters, math,
+                            int(bec_compat), threads, max_frames, min_fec, ct.byref(res), _p(totals), None)
+        out = {k: v[:nx] for k, v in arrs.items()}
+        out["totals"] = totals[:4 * nx].reshape(nx, 4)  # frames, fec, bec, iters
+        return out
+
+
+def mt64_stream(seed, n):
+    out = np.zeros(n, np.uint64)
+    lib().orc_mt64_stream(seed, n, _p(out))
+    return out
+
+
+# ---- reference binaries built into oracle/_ref (present only where /root/reference is) ----
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+REF_DUMP = os.path.join(REF_DIR, "ref_dump")
+REF_SIM = os.path.join(REF_DIR, "ldpcsim_ref")
+REF_LIB = os.path.join(REF_DIR, "libldpc_ref.so")
+
+
+def have_ref():
+    return os.path.exists(REF_DUMP)
+
+
+def ref_dump(h, g, chan, dec, iters, early, seed, x, skip, count, tmp):
+    """Run the reference through oracle/_ref/ref_dump; returns the same dict as Code.run_frames."""
+    subprocess.check_call([REF_DUMP, h, g or "-", chan, dec, str(iters), str(int(early)), str(seed),
+                           repr(float(x)), str(skip), str(count), tmp], stdout=subprocess.DEVNULL)
+    raw = open(tmp, "rb").read()
+    nc, cnt = np.frombuffer(raw, np.int32, 2)
+    rec = np.dtype([("iters", "<i4"), ("bit_errors", "<i4"), ("hard", "u1", (nc,)), ("llr_in", "<f8", (nc,)),
+                    ("llr_out", "<f8", (nc,)), ("codeword", "u1", (nc,))])
+    a = np.frombuffer(raw, rec, cnt, 8)
+    return {k: np.ascontiguousarray(a[k]) for k in rec.names}

@@ -1,0 +1,122 @@
+"""Pin the CPU oracle (oracle/ldpc_oracle.c) against fixtures produced by the reference itself.
+
+The reference has no decoder vectors of its own; tests/golden/*.npz were generated
+by tests/golden/make_golden.py from the unmodified reference built into oracle/_ref/.
+libm mode must reproduce them bit for bit (doubles compared with ==).
+"""
+import numpy as np
+import pytest
+
+import orc
+
+
+@pytest.fixture(scope="module")
+def codes():
+    return {False: orc.Code(orc.H_TXT), True: orc.Code(orc.H_TXT, orc.G_TXT)}
+
+
+def _run(codes, case, **kw):
+    g, ch, dec, it, early, seed, x, skip, cnt = case
+    return codes[bool(g)].run_frames(ch, x, seed=seed, skip=skip, count=cnt, min_sum=(dec == "BP_MS"),
+                                     early_term=bool(early), iters=it, bec_compat=True, **kw)
+
+
+def test_code_parameters(codes):
+    c = codes[True]
+    # SURVEY §8 sizes of tests/code/h.txt and g.txt
+    assert (c.nc, c.mc, c.nnz, c.nct, c.mct, c.kct, c.kc, c.max_degree) == (1152, 1024, 3456, 1024, 896, 128, 128, 15)
+    assert (c.g_rows, c.g_cols, c.g_nnz) == (128, 1152, 18912)
+    assert list(c.puncture) == list(range(256, 384)) and c.num_shorten == 0
+    assert c.rank() == 1021
+
+
+def test_frames_bit_exact(codes, golden_frames, golden_sim):
+    for name, case in golden_sim["cases"].items():
+        r = _run(codes, case)
+        for k in ("iters", "bit_errors", "hard", "codeword", "llr_in", "llr_out"):
+            ref = golden_frames[f"{name}/{k}"]
+            got = r[k].astype(ref.dtype)
+            assert np.array_equal(ref, got), f"{name}/{k}: {np.sum(ref != got)} mismatches"
+
+
+def test_counters_bit_exact(codes, golden_counters, golden_sim):
+    for name, case in golden_sim["counter_cases"].items():
+        r = _run(codes, case, want_vectors=False)
+        assert np.array_equal(golden_counters[f"{name}/iters"], r["iters"]), name
+        assert np.array_equal(golden_counters[f"{name}/bit_errors"], r["bit_errors"]), name
+
+
+def test_first_frame_error_is_frame_1216(golden_counters):
+    # two frame errors in the first 2000 frames, the first one at (1-based) frame 1217
+    be = golden_counters["awgn_bp_m4/bit_errors"]
+    assert np.flatnonzero(be)[0] == 1216 and np.count_nonzero(be) == 2
+
+
+def _fmt(x, fec, bec, frames, iters, nc):
+    return "%f %.3e %.3e %d %.3e" % (x, fec / frames, bec / (frames * nc), frames, iters / frames)
+
+
+def test_simulate_matches_reference_cli(codes, golden_sim):
+    """orc_simulate == the reference CLI's result file (ldpcsim.cpp:97-263), 1 thread."""
+    G = {"<G>": orc.G_TXT}
+    for name, entry in golden_sim["cli"].items():
+        a = [G.get(s, s) for s in entry["args"]]
+        opt = {"-s": "0", "-i": "50", "--channel": "AWGN", "--decoding": "BP", "--max-frames": str(10**10),
+               "--frame-error-count": "50", "-G": ""}
+        i, early = 3, True
+        while i < len(a):
+            if a[i] == "--no-early-term":
+                early, i = False, i + 1
+            else:
+                opt[a[i]] = a[i + 1]
+                i += 2
+        code = codes[bool(opt["-G"])]
+        res = code.simulate(opt["--channel"], [float(a[0]), float(a[1]), float(a[2])], seed=int(opt["-s"]),
+                            min_sum=opt["--decoding"] == "BP_MS", early_term=early, iters=int(opt["-i"]),
+                            bec_compat=True, max_frames=int(opt["--max-frames"]),
+                            min_fec=int(opt["--frame-error-count"]))
+        lines = ["snr fer ber frames avg_iter"]
+        xs = np.arange(len(res["totals"]))
+        vals = []
+        v = float(a[0])
+        while v < float(a[1]):
+            vals.append(v)
+            v += float(a[2])
+        if opt["--channel"] != "AWGN":
+            vals = vals[::-1]
+        for i in xs:
+            frames, fec, bec, iters = (int(t) for t in res["totals"][i])
+            # the reference only writes a line when a frame error happened, and the line reflects
+            # the counters at the LAST frame error
+            if fec == 0:
+                lines.append("")
+                continue
+            lines.append("%f %.3e %.3e %d %.3e" % (vals[i], res["fer"][i], res["ber"][i], res["frames"][i],
+                                                  res["avg_iter"][i]))
+        assert lines == entry["lines"], name
+
+
+def test_mt19937_64_known_answer():
+    # ISO C++ [rand.predef]: the 10000th invocation of a default-constructed mt19937_64 is 9981545732273789042
+    s = orc.mt64_stream(5489, 10000)
+    assert int(s[-1]) == 9981545732273789042
+
+
+def test_detmath_close_to_libm():
+    rng = np.random.default_rng(0)
+    L = orc.lib()
+    for x in -40 * rng.random(2000):
+        a, b = L.orc_exp(orc.MATH_DET, x), L.orc_exp(orc.MATH_LIBM, x)
+        assert abs(a - b) <= 2 * np.spacing(b)
+    for q in 0.5 + 1.5 * rng.random(2000):
+        a, b = L.orc_log(orc.MATH_DET, q), L.orc_log(orc.MATH_LIBM, q)
+        assert abs(a - b) <= 2 * np.spacing(abs(b)) + 1e-300
+
+
+def test_det_mode_within_tolerance_of_libm(codes, golden_frames):
+    """north_star tolerance: LLRs within 1e-5, hard decisions / iteration counts exact (converged frames)."""
+    r = codes[False].run_frames("AWGN", -4.0, seed=0, count=8, math=orc.MATH_DET)
+    assert np.array_equal(r["iters"], golden_frames["awgn_bp_m4/iters"])
+    assert np.array_equal(r["hard"], golden_frames["awgn_bp_m4/hard"])
+    assert np.max(np.abs(r["llr_in"] - golden_frames["awgn_bp_m4/llr_in"])) < 1e-12
+    assert np.max(np.abs(r["llr_out"] - golden_frames["awgn_bp_m4/llr_out"])) < 1e-5

@@ -1,0 +1,149 @@
+/*
+ * ldpc_amd.h — C ABI of libldpc.so, the MI355X-native drop-in for heat1q/libldpc's shared library.
+ *
+ * Part 1 re-exports, symbol for symbol and struct for struct, the six entry points of the
+ * reference's src/shared.cpp:9-78 that pyLDPC/ldpc.py binds through ctypes, so an existing
+ * `LDPC(pc_file, gen_file, lib="…/libldpc.so")` keeps working unchanged.
+ * Part 2 is the batch interface the HIP path sits behind: the reference's per-frame virtual calls
+ * (src/sim/channel.h:17-24 invoked at src/sim/ldpcsim.cpp:158-174) become one call per batch of
+ * frames.  Plain pointers and sizes only; device pointers are accepted wherever a buffer is named
+ * "device or host".
+ */
+#ifndef LDPC_AMD_H
+#define LDPC_AMD_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* Part 1 — reference C ABI (src/core/functions.h:107-127, src/sim/ldpcsim.h:23-31)            */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct
+{
+    bool earlyTerm;
+    uint32_t iterations;
+    const char *type; /* "BP_MS" selects min-sum, anything else sum-product (decoder.h:73-80) */
+} decoder_param;
+
+typedef struct
+{
+    uint64_t seed;
+    double xRange[3]; /* MIN, MAX (exclusive), STEP */
+    const char *type; /* "AWGN" | "BSC" | "BEC" */
+} channel_param;
+
+typedef struct
+{
+    uint32_t threads;  /* accepted for compatibility; the GPU batch replaces OpenMP threads */
+    uint64_t maxFrames;
+    uint64_t fec;
+    const char *resultFile;
+} simulation_param;
+
+typedef struct
+{
+    double *fer;
+    double *ber;
+    double *avg_iter;
+    double *time;
+    uint64_t *fec;
+    uint64_t *frames;
+} sim_results_t;
+
+/* replaces shared.cpp:11-24 — (re)creates the process-global code; file errors print and exit(1) */
+void ldpc_setup(const char *pcFile, const char *genFile, int *n, int *m, int *nct, int *mct);
+/* replaces shared.cpp:26-30 — blocks until done; writes results->x[i] per channel point; polls *stopFlag */
+void simulate(decoder_param decoderParams, channel_param channelParam, simulation_param simParam,
+              sim_results_t *results, bool *stopFlag);
+/* replaces shared.cpp:32-35 */
+int calculate_rank(void);
+/* replaces shared.cpp:37-45 — infoWord[kct] -> codeWord[nct] (transmitted positions) */
+void encode(uint8_t *infoWord, uint8_t *codeWord);
+/* replaces shared.cpp:47-65 — llr[nct] in, llrOut[nct] out, returns the iteration count */
+int decode(decoder_param decoderParams, double *llr, double *llrOut);
+/* replaces shared.cpp:67-77 — word[nc] -> syndrome[mc] */
+void syndrome(uint8_t *word, uint8_t *syndrome);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Part 2 — batch interface (HIP shim)                                                         */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct ldpc_hip_ctx ldpc_hip_ctx;
+
+enum
+{
+    LDPC_HIP_AWGN = 1, /* ldpcsim.h:15-20 */
+    LDPC_HIP_BSC = 2,
+    LDPC_HIP_BEC = 3
+};
+
+/* outputs of a batch of n frames; each pointer is device or host memory, NULL = not wanted */
+typedef struct
+{
+    uint32_t *iters;      /* [n]      iteration count as returned by ldpc_decoder::decode (decoder.cpp:74-77) */
+    uint32_t *bit_errors; /* [n]      ldpcsim.cpp:184-188, transmitted positions only */
+    uint8_t *hard;        /* [n][nc]  estimate() */
+    double *llr_out;      /* [n][nc]  llr_out() (BEC: symbol values 0,1,'E') */
+    double *llr_in;       /* [n][nc]  the decoder input the channel produced */
+    uint8_t *codeword;    /* [n][nc]  transmitted codeword */
+} ldpc_hip_out;
+
+/* number of visible GPUs (0 when none); never throws */
+int ldpc_hip_device_count(void);
+/* message of the last failed ldpc_hip_* call on this thread */
+const char *ldpc_hip_last_error(void);
+
+/* parse the code (host only; the GPU is touched lazily by the first decode). NULL on error. */
+ldpc_hip_ctx *ldpc_hip_create(const char *pcFile, const char *genFile, int device);
+void ldpc_hip_destroy(ldpc_hip_ctx *ctx);
+/* info[0..9] = nc, mc, nnz, nct, mct, kct, kc, max_degree, lds_resident(0/1), lds_bytes_per_frame */
+void ldpc_hip_code_info(const ldpc_hip_ctx *ctx, int64_t info[10]);
+/* BEC: 1 = reproduce the reference's out-of-bounds read for erased degree-1 variable nodes
+   (they emit 0); 0 (default) = defined semantics, they emit an erasure */
+void ldpc_hip_set_bec_compat(ldpc_hip_ctx *ctx, int compat);
+
+/* decode n frames of given LLRs llr_in[n][nc] (column order, device or host). 0 on success. */
+int ldpc_hip_decode_batch(ldpc_hip_ctx *ctx, decoder_param dec, uint64_t n, const double *llr_in,
+                          const ldpc_hip_out *out, void *hip_stream);
+
+/* channel point x of stream mt19937_64(seed): set_channel_param semantics, frame position := 0 */
+int ldpc_hip_stream_begin(ldpc_hip_ctx *ctx, int channel, uint64_t seed, double x);
+/* advance the stream by n frames without decoding them */
+int ldpc_hip_stream_skip(ldpc_hip_ctx *ctx, uint64_t n, void *hip_stream);
+/* channel + LLR init + decode of the next n frames of the stream, fused in one launch */
+int ldpc_hip_stream_decode(ldpc_hip_ctx *ctx, decoder_param dec, uint64_t n, const ldpc_hip_out *out,
+                           void *hip_stream);
+/* frames consumed / raw 64-bit draws consumed since ldpc_hip_stream_begin */
+uint64_t ldpc_hip_stream_frame(const ldpc_hip_ctx *ctx);
+uint64_t ldpc_hip_stream_raw_draws(const ldpc_hip_ctx *ctx);
+int ldpc_hip_synchronize(ldpc_hip_ctx *ctx, void *hip_stream);
+
+/* time kernels with HIP events recorded on the launch stream: which = 0 the decode kernel of the last
+   batch, 1 the noise-stream kernels (mt19937_64 generate + polar scan) of the last batch; milliseconds */
+void ldpc_hip_set_profiling(ldpc_hip_ctx *ctx, int on);
+float ldpc_hip_last_ms(ldpc_hip_ctx *ctx, int which);
+
+/* first n outputs of std::mt19937_64(seed) starting at output `first`, produced by the device
+   generator (jump-ahead + parallel chunks); out is device or host memory */
+int ldpc_hip_mt64(ldpc_hip_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, uint64_t *out, void *hip_stream);
+
+/* the simulation loop of ldpc_sim::start (ldpcsim.cpp:97-263) on one context; totals[4*i..] =
+   {frames, fec, bec, iters} per channel point.  Returns the number of channel points, <0 on error. */
+int ldpc_hip_simulate(ldpc_hip_ctx *ctx, decoder_param dec, channel_param ch, simulation_param sim,
+                      sim_results_t *results, uint64_t *totals, bool *stopFlag, int cli_output);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_AMD_H */

@@ -1,0 +1,207 @@
+"""ctypes binding of the batch interface (Part 2 of include/ldpc_amd.h)."""
+import ctypes as ct
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libldpc.so")
+
+AWGN, BSC, BEC = 1, 2, 3
+CHANNELS = {"AWGN": AWGN, "BSC": BSC, "BEC": BEC}
+
+
+class decoder_param(ct.Structure):
+    _fields_ = [("earlyTerm", ct.c_bool), ("iterations", ct.c_uint32), ("type", ct.c_char_p)]
+
+
+class channel_param(ct.Structure):
+    _fields_ = [("seed", ct.c_uint64), ("xRange", ct.c_double * 3), ("type", ct.c_char_p)]
+
+
+class simulation_param(ct.Structure):
+    _fields_ = [("threads", ct.c_uint32), ("maxFrames", ct.c_uint64), ("fec", ct.c_uint64),
+                ("resultFile", ct.c_char_p)]
+
+
+class sim_results_t(ct.Structure):
+    _fields_ = [("fer", ct.POINTER(ct.c_double)), ("ber", ct.POINTER(ct.c_double)),
+                ("avg_iter", ct.POINTER(ct.c_double)), ("time", ct.POINTER(ct.c_double)),
+                ("fec", ct.POINTER(ct.c_uint64)), ("frames", ct.POINTER(ct.c_uint64))]
+
+
+class ldpc_hip_out(ct.Structure):
+    _fields_ = [("iters", ct.c_void_p), ("bit_errors", ct.c_void_p), ("hard", ct.c_void_p),
+                ("llr_out", ct.c_void_p), ("llr_in", ct.c_void_p), ("codeword", ct.c_void_p)]
+
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """Load libldpc.so; raises if it has not been built (python -m libldpc_amd.build)."""
+    global _lib
+    if _lib is not None and path == LIB_PATH:
+        return _lib
+    if not os.path.exists(path):
+        raise OSError(f"{path} is missing: build the HIP extension first (python -m libldpc_amd.build); "
+                      "there is no CPU fallback")
+    L = ct.CDLL(path)
+    vp, u64, i32 = ct.c_void_p, ct.c_uint64, ct.c_int
+    L.ldpc_hip_device_count.restype = i32
+    L.ldpc_hip_last_error.restype = ct.c_char_p
+    L.ldpc_hip_create.restype = vp
+    L.ldpc_hip_create.argtypes = [ct.c_char_p, ct.c_char_p, i32]
+    L.ldpc_hip_destroy.argtypes = [vp]
+    L.ldpc_hip_code_info.argtypes = [vp, ct.POINTER(ct.c_int64)]
+    L.ldpc_hip_set_bec_compat.argtypes = [vp, i32]
+    L.ldpc_hip_decode_batch.restype = i32
+    L.ldpc_hip_decode_batch.argtypes = [vp, decoder_param, u64, vp, ct.POINTER(ldpc_hip_out), vp]
+    L.ldpc_hip_stream_begin.restype = i32
+    L.ldpc_hip_stream_begin.argtypes = [vp, i32, u64, ct.c_double]
+    L.ldpc_hip_stream_skip.restype = i32
+    L.ldpc_hip_stream_skip.argtypes = [vp, u64, vp]
+    L.ldpc_hip_stream_decode.restype = i32
+    L.ldpc_hip_stream_decode.argtypes = [vp, decoder_param, u64, ct.POINTER(ldpc_hip_out), vp]
+    L.ldpc_hip_stream_frame.restype = u64
+    L.ldpc_hip_stream_frame.argtypes = [vp]
+    L.ldpc_hip_stream_raw_draws.restype = u64
+    L.ldpc_hip_stream_raw_draws.argtypes = [vp]
+    L.ldpc_hip_synchronize.restype = i32
+    L.ldpc_hip_synchronize.argtypes = [vp, vp]
+    L.ldpc_hip_mt64.restype = i32
+    L.ldpc_hip_mt64.argtypes = [vp, u64, u64, u64, vp, vp]
+    L.ldpc_hip_set_profiling.argtypes = [vp, i32]
+    L.ldpc_hip_last_ms.restype = ct.c_float
+    L.ldpc_hip_last_ms.argtypes = [vp, i32]
+    L.ldpc_hip_simulate.restype = i32
+    L.ldpc_hip_simulate.argtypes = [vp, decoder_param, channel_param, simulation_param, ct.POINTER(sim_results_t),
+                                    vp, ct.POINTER(ct.c_bool), i32]
+    if path == LIB_PATH:
+        _lib = L
+    return L
+
+
+def _ptr(buf):
+    """Address of a numpy array or of a torch tensor (host or device)."""
+    if buf is None:
+        return None
+    if isinstance(buf, np.ndarray):
+        assert buf.flags["C_CONTIGUOUS"]
+        return buf.ctypes.data
+    if hasattr(buf, "data_ptr"):
+        assert buf.is_contiguous()
+        return buf.data_ptr()
+    raise TypeError(f"unsupported buffer type {type(buf)}")
+
+
+def _dec(early_term, iterations, decoding):
+    return decoder_param(bool(early_term), int(iterations), decoding.encode())
+
+
+class HipDecoder:
+    """One code on one GPU.  All batch calls take numpy arrays or torch tensors as buffers."""
+
+    OUT_SPEC = {"iters": (np.uint32, False), "bit_errors": (np.uint32, False), "hard": (np.uint8, True),
+                "llr_out": (np.float64, True), "llr_in": (np.float64, True), "codeword": (np.uint8, True)}
+
+    def __init__(self, pc_file, gen_file="", device=0, lib=LIB_PATH):
+        self.lib = load_library(lib)
+        self.ctx = self.lib.ldpc_hip_create(pc_file.encode(), gen_file.encode(), device)
+        if not self.ctx:
+            raise RuntimeError("ldpc_hip_create: " + self.lib.ldpc_hip_last_error().decode())
+        info = (ct.c_int64 * 10)()
+        self.lib.ldpc_hip_code_info(self.ctx, info)
+        (self.nc, self.mc, self.nnz, self.nct, self.mct, self.kct, self.kc, self.max_degree, lds,
+         self.lds_bytes) = list(info)
+        self.lds_resident = bool(lds)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.ldpc_hip_destroy(self.ctx)
+            self.ctx = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: " + self.lib.ldpc_hip_last_error().decode())
+
+    def _outs(self, n, want, out):
+        """Build the output struct; `want` names host (numpy) outputs to allocate, `out` passes buffers."""
+        bufs = dict(out or {})
+        for name in want:
+            if name not in bufs:
+                dt, per_bit = self.OUT_SPEC[name]
+                bufs[name] = np.zeros((n, self.nc) if per_bit else (n,), dt)
+        s = ldpc_hip_out(*[_ptr(bufs.get(k)) for k in ("iters", "bit_errors", "hard", "llr_out", "llr_in", "codeword")])
+        return s, bufs
+
+    def set_bec_compat(self, on):
+        self.lib.ldpc_hip_set_bec_compat(self.ctx, int(on))
+
+    def decode_batch(self, llr_in, early_term=True, iterations=50, decoding="BP",
+                     want=("iters", "hard", "llr_out"), out=None, stream=None):
+        """Decode llr_in[n][nc] (column order)."""
+        n = int(llr_in.shape[0])
+        s, bufs = self._outs(n, want, out)
+        self._check(self.lib.ldpc_hip_decode_batch(self.ctx, _dec(early_term, iterations, decoding), n, _ptr(llr_in),
+                                                   ct.byref(s), stream), "ldpc_hip_decode_batch")
+        return bufs
+
+    def stream_begin(self, channel, seed, x):
+        ch = CHANNELS[channel] if isinstance(channel, str) else int(channel)
+        self._check(self.lib.ldpc_hip_stream_begin(self.ctx, ch, int(seed), float(x)), "ldpc_hip_stream_begin")
+
+    def stream_skip(self, n, stream=None):
+        self._check(self.lib.ldpc_hip_stream_skip(self.ctx, int(n), stream), "ldpc_hip_stream_skip")
+
+    def stream_decode(self, n, early_term=True, iterations=50, decoding="BP", want=("iters", "bit_errors"),
+                      out=None, stream=None):
+        s, bufs = self._outs(int(n), want, out)
+        self._check(self.lib.ldpc_hip_stream_decode(self.ctx, _dec(early_term, iterations, decoding), int(n),
+                                                    ct.byref(s), stream), "ldpc_hip_stream_decode")
+        return bufs
+
+    @property
+    def stream_frame(self):
+        return self.lib.ldpc_hip_stream_frame(self.ctx)
+
+    @property
+    def stream_raw_draws(self):
+        return self.lib.ldpc_hip_stream_raw_draws(self.ctx)
+
+    def synchronize(self, stream=None):
+        self._check(self.lib.ldpc_hip_synchronize(self.ctx, stream), "ldpc_hip_synchronize")
+
+    def set_profiling(self, on=True):
+        self.lib.ldpc_hip_set_profiling(self.ctx, int(on))
+
+    def last_ms(self, which=0):
+        return float(self.lib.ldpc_hip_last_ms(self.ctx, which))
+
+    def mt64(self, seed, first, n):
+        out = np.zeros(int(n), np.uint64)
+        self._check(self.lib.ldpc_hip_mt64(self.ctx, int(seed), int(first), int(n), _ptr(out), None), "ldpc_hip_mt64")
+        return out
+
+    def simulate(self, channel, x_range, seed=0, early_term=True, iterations=50, decoding="BP",
+                 max_frames=10**10, fec=50, result_file="", cli_output=False):
+        n_max = max(1, int(np.ceil((x_range[1] - x_range[0]) / x_range[2])) + 2)
+        arrs = {k: np.zeros(n_max, np.float64) for k in ("fer", "ber", "avg_iter", "time")}
+        arrs["fec"] = np.zeros(n_max, np.uint64)
+        arrs["frames"] = np.zeros(n_max, np.uint64)
+        res = sim_results_t(*[arrs[k].ctypes.data_as(ct.POINTER(ct.c_double if arrs[k].dtype == np.float64
+                                                                 else ct.c_uint64))
+                              for k in ("fer", "ber", "avg_iter", "time", "fec", "frames")])
+        totals = np.zeros(4 * n_max, np.uint64)
+        stop = ct.c_bool(False)
+        ch = channel_param(int(seed), (ct.c_double * 3)(*x_range), channel.encode())
+        sp = simulation_param(1, int(max_frames), int(fec), result_file.encode())
+        nx = self.lib.ldpc_hip_simulate(self.ctx, _dec(early_term, iterations, decoding), ch, sp, ct.byref(res),
+                                        totals.ctypes.data, ct.byref(stop), int(cli_output))
+        if nx < 0:
+            raise RuntimeError("ldpc_hip_simulate: " + self.lib.ldpc_hip_last_error().decode())
+        out = {k: v[:nx] for k, v in arrs.items()}
+        out["totals"] = totals[:4 * nx].reshape(nx, 4)
+        return out

@@ -1,0 +1,70 @@
+"""Build the native library and CLI in-tree with hipcc for gfx950.
+
+    python -m libldpc_amd.build            # libldpc_amd/libldpc.so + libldpc_amd/ldpcsim
+
+Objects are cached under libldpc_amd/csrc/build/ and rebuilt when a source or header changes.
+The shared object keeps the reference's name (libldpc.so, CMakeLists.txt:21) so that
+pyLDPC's `LDPC(..., lib=<path>)` can be pointed at it unchanged.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(PKG, "libldpc.so")
+CLI = os.path.join(PKG, "ldpcsim")
+
+LIB_SOURCES = ["kernels.hip", "rng_kernels.hip", "engine.cpp", "api.cpp", "sim.cpp", "code.cpp", "plan.cpp", "mt64.cpp"]
+CLI_SOURCES = ["ldpcsim_main.cpp"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: every fused multiply-add is written explicitly (detmath.h); results must not
+# depend on the compiler's contraction choices.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    hs.append(os.path.join(os.path.dirname(PKG), "include", "ldpc_amd.h"))
+    return hs
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src + ".o")
+    path = os.path.join(CSRC, src)
+    if _stale(obj, [path] + _headers()):
+        cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+        subprocess.check_call(cmd)
+    return obj
+
+
+def build(verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = LIB_SOURCES + [s for s in CLI_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = dict(zip(srcs, ex.map(_compile, srcs)))
+    lib_objs = [objs[s] for s in LIB_SOURCES]
+    if _stale(LIB, lib_objs):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-o", LIB] + lib_objs)
+    cli_objs = [objs[s] for s in CLI_SOURCES if s in objs]
+    if cli_objs and _stale(CLI, cli_objs + [LIB]):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-o", CLI] + cli_objs +
+                              ["-L" + PKG, "-l:libldpc.so", "-Wl,-rpath,$ORIGIN"])
+    if verbose:
+        print("built", LIB, "and", CLI if cli_objs else "(no CLI)")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(verbose=True)
+    sys.exit(0)

@@ -1,0 +1,326 @@
+// api.cpp — the C ABI of libldpc.so (include/ldpc_amd.h).
+//
+// Part 1 mirrors the reference's src/shared.cpp:9-78 (same symbols, same struct layouts, same
+// process-global state and error behaviour: failures print a message and exit(EXIT_FAILURE)).
+// Part 2 is the batch interface over ldpc_amd::Engine.
+#include "../../include/ldpc_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+#include "sim.hpp"
+
+using namespace ldpc_amd;
+
+struct ldpc_hip_ctx
+{
+    std::unique_ptr<Engine> eng;
+    MtStream aux;
+    DeviceBuffer aux_out;
+};
+
+namespace
+{
+thread_local std::string g_err;
+
+std::unique_ptr<Engine> g_engine; // shared.cpp:4-5: one code + one decoder per process
+bool g_sticky_min_sum = false;    // decoder.h:73-80: set_param never switches back from BP_MS
+
+DecParams to_params(const decoder_param &p)
+{
+    DecParams d;
+    d.early_term = p.earlyTerm;
+    d.iterations = p.iterations;
+    d.min_sum = p.type && std::strcmp(p.type, "BP_MS") == 0;
+    return d;
+}
+
+int channel_from(const char *type)
+{
+    if (type && !std::strcmp(type, "AWGN"))
+        return kAwgn;
+    if (type && !std::strcmp(type, "BSC"))
+        return kBsc;
+    if (type && !std::strcmp(type, "BEC"))
+        return kBec;
+    return 0;
+}
+
+[[noreturn]] void die(const char *where, const std::exception &e)
+{
+    std::cout << "Error: " << where << " " << e.what() << std::endl;
+    std::exit(EXIT_FAILURE);
+}
+
+template <typename F>
+int guarded(F &&f)
+{
+    try
+    {
+        f();
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+BatchOut to_out(const ldpc_hip_out *o)
+{
+    BatchOut b;
+    if (o)
+    {
+        b.iters = o->iters, b.bit_errors = o->bit_errors, b.hard = o->hard;
+        b.llr_out = o->llr_out, b.llr_in = o->llr_in, b.codeword = o->codeword;
+    }
+    return b;
+}
+} // namespace
+
+extern "C"
+{
+
+// ------------------------------------------------------------------------------------------------
+// Part 1 — reference ABI
+// ------------------------------------------------------------------------------------------------
+void ldpc_setup(const char *pcFile, const char *genFile, int *n, int *m, int *nct, int *mct)
+{
+    try
+    {
+        g_engine = std::make_unique<Engine>(pcFile ? pcFile : "", genFile ? genFile : "", 0);
+    }
+    catch (const std::exception &e)
+    {
+        die("ldpc_code():", e); // ldpc.cpp:16-20
+    }
+    g_sticky_min_sum = false;
+    const LdpcCode &c = g_engine->code();
+    *n = c.nc(), *m = c.mc(), *nct = c.nct(), *mct = c.mct();
+}
+
+void simulate(decoder_param decoderParams, channel_param channelParam, simulation_param simParam,
+              sim_results_t *results, bool *stopFlag)
+{
+    SimRequest rq;
+    rq.dec = to_params(decoderParams);
+    rq.channel = channel_from(channelParam.type);
+    rq.seed = channelParam.seed;
+    for (int i = 0; i < 3; ++i)
+        rq.x_range[i] = channelParam.xRange[i];
+    rq.max_frames = simParam.maxFrames;
+    rq.min_fec = simParam.fec;
+    rq.result_file = simParam.resultFile ? simParam.resultFile : "";
+    rq.cli_output = false; // the reference library is built with LIB_SHARED (CMakeLists.txt:22)
+    try
+    {
+        if (!g_engine)
+            throw std::runtime_error("ldpc_setup() has not been called");
+        if (!rq.channel)
+            throw std::runtime_error("No channel selected."); // ldpcsim.cpp:74
+        g_engine->bec_deg1_compat = std::getenv("LDPC_AMD_BEC_COMPAT") != nullptr;
+        run_simulation(*g_engine, rq, results, nullptr, stopFlag);
+    }
+    catch (const std::exception &e)
+    {
+        die("ldpc_sim::ldpc_sim()", e);
+    }
+}
+
+int calculate_rank(void) { return g_engine ? g_engine->code().H.rank() : 0; }
+
+void encode(uint8_t *infoWord, uint8_t *codeWord)
+{
+    if (!g_engine)
+        return;
+    const LdpcCode &c = g_engine->code();
+    std::vector<uint8_t> cw(std::max(c.nc(), c.G.cols), 0);
+    if (c.has_G())
+    {
+        // the reference reads kct() info bits and multiplies by G (kc() rows)
+        std::vector<uint8_t> u(std::max(c.G.rows, c.kct()), 0);
+        for (int i = 0; i < c.kct(); ++i)
+            u[i] = infoWord[i] != 0;
+        c.G.multiply_left(u.data(), cw.data());
+    }
+    else
+        std::cout << "Error: encode() no generator matrix loaded" << std::endl;
+    for (int i = 0; i < c.nct(); ++i)
+        codeWord[i] = cw[c.bit_pos[i]];
+}
+
+int decode(decoder_param decoderParams, double *llr, double *llrOut)
+{
+    try
+    {
+        if (!g_engine)
+            throw std::runtime_error("ldpc_setup() has not been called");
+        const LdpcCode &c = g_engine->code();
+        DecParams p = to_params(decoderParams);
+        g_sticky_min_sum = g_sticky_min_sum || p.min_sum;
+        p.min_sum = g_sticky_min_sum;
+        std::vector<double> in(c.nc(), 0.0), out(c.nc(), 0.0); // punctured and shortened stay 0.0 (shared.cpp:50)
+        for (int i = 0; i < c.nct(); ++i)
+            in[c.bit_pos[i]] = llr[i];
+        uint32_t iters = 0;
+        BatchOut o;
+        o.iters = &iters;
+        o.llr_out = out.data();
+        g_engine->decode_llr(p, 1, in.data(), o, nullptr);
+        for (int i = 0; i < c.nct(); ++i)
+            llrOut[i] = out[c.bit_pos[i]];
+        return static_cast<int>(iters);
+    }
+    catch (const std::exception &e)
+    {
+        die("decode()", e);
+    }
+}
+
+void syndrome(uint8_t *word, uint8_t *synd)
+{
+    if (!g_engine)
+        return;
+    const LdpcCode &c = g_engine->code();
+    std::vector<uint8_t> s(c.mc(), 0);
+    c.H.multiply_right(word, s.data());
+    std::memcpy(synd, s.data(), s.size());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Part 2 — batch interface
+// ------------------------------------------------------------------------------------------------
+int ldpc_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *ldpc_hip_last_error(void) { return g_err.c_str(); }
+
+ldpc_hip_ctx *ldpc_hip_create(const char *pcFile, const char *genFile, int device)
+{
+    ldpc_hip_ctx *ctx = nullptr;
+    if (guarded([&] {
+            auto c = std::make_unique<ldpc_hip_ctx>();
+            c->eng = std::make_unique<Engine>(pcFile ? pcFile : "", genFile ? genFile : "", device);
+            ctx = c.release();
+        }) != 0)
+        return nullptr;
+    return ctx;
+}
+
+void ldpc_hip_destroy(ldpc_hip_ctx *ctx) { delete ctx; }
+
+void ldpc_hip_code_info(const ldpc_hip_ctx *ctx, int64_t info[10])
+{
+    const LdpcCode &c = ctx->eng->code();
+    const Plan &p = ctx->eng->plan();
+    info[0] = c.nc(), info[1] = c.mc(), info[2] = c.nnz(), info[3] = c.nct(), info[4] = c.mct();
+    info[5] = c.kct(), info[6] = c.kc(), info[7] = c.max_degree, info[8] = p.lds_ok;
+    info[9] = static_cast<int64_t>(p.lds_bytes);
+}
+
+void ldpc_hip_set_bec_compat(ldpc_hip_ctx *ctx, int compat) { ctx->eng->bec_deg1_compat = compat != 0; }
+
+int ldpc_hip_decode_batch(ldpc_hip_ctx *ctx, decoder_param dec, uint64_t n, const double *llr_in,
+                          const ldpc_hip_out *out, void *hip_stream)
+{
+    return guarded([&] { ctx->eng->decode_llr(to_params(dec), n, llr_in, to_out(out), hip_stream); });
+}
+
+int ldpc_hip_stream_begin(ldpc_hip_ctx *ctx, int channel, uint64_t seed, double x)
+{
+    return guarded([&] { ctx->eng->stream_begin(channel, seed, x); });
+}
+
+int ldpc_hip_stream_skip(ldpc_hip_ctx *ctx, uint64_t n, void *hip_stream)
+{
+    return guarded([&] { ctx->eng->stream_skip(n, hip_stream); });
+}
+
+int ldpc_hip_stream_decode(ldpc_hip_ctx *ctx, decoder_param dec, uint64_t n, const ldpc_hip_out *out,
+                           void *hip_stream)
+{
+    return guarded([&] { ctx->eng->stream_decode(to_params(dec), n, to_out(out), hip_stream); });
+}
+
+uint64_t ldpc_hip_stream_frame(const ldpc_hip_ctx *ctx) { return ctx->eng->stream_frame(); }
+uint64_t ldpc_hip_stream_raw_draws(const ldpc_hip_ctx *ctx) { return ctx->eng->stream_raw_draws(); }
+
+int ldpc_hip_synchronize(ldpc_hip_ctx *ctx, void *hip_stream)
+{
+    return guarded([&] { ctx->eng->synchronize(hip_stream); });
+}
+
+void ldpc_hip_set_profiling(ldpc_hip_ctx *ctx, int on)
+{
+    guarded([&] { ctx->eng->set_profiling(on != 0); });
+}
+
+float ldpc_hip_last_ms(ldpc_hip_ctx *ctx, int which) { return ctx->eng->last_ms(which); }
+
+int ldpc_hip_mt64(ldpc_hip_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, uint64_t *out, void *hip_stream)
+{
+    return guarded([&] {
+        if (ldpc_hip_device_count() <= ctx->eng->device())
+            throw std::runtime_error("no usable HIP device (MI355X required)");
+        if (hipSetDevice(ctx->eng->device()) != hipSuccess)
+            throw std::runtime_error("hipSetDevice failed");
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);
+        ctx->aux.reset(seed);
+        uint64_t done = 0;
+        while (done < n)
+        {
+            const uint64_t k = std::min<uint64_t>(n - done, 64ull << 20);
+            const uint64_t *raw = ctx->aux.generate(first + done, k, hip_stream);
+            hipPointerAttribute_t attr;
+            bool dev = hipPointerGetAttributes(&attr, out) == hipSuccess && attr.type == hipMemoryTypeDevice;
+            if (!dev)
+                (void)hipGetLastError();
+            if (hipMemcpyAsync(out + done, raw, 8 * k, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s) !=
+                    hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                throw std::runtime_error("copy of mt19937_64 words failed");
+            done += k;
+        }
+    });
+}
+
+int ldpc_hip_simulate(ldpc_hip_ctx *ctx, decoder_param dec, channel_param ch, simulation_param sim,
+                      sim_results_t *results, uint64_t *totals, bool *stopFlag, int cli_output)
+{
+    int n = -1;
+    int rc = guarded([&] {
+        SimRequest rq;
+        rq.dec = to_params(dec);
+        rq.channel = channel_from(ch.type);
+        if (!rq.channel)
+            throw std::runtime_error("No channel selected.");
+        rq.seed = ch.seed;
+        for (int i = 0; i < 3; ++i)
+            rq.x_range[i] = ch.xRange[i];
+        rq.max_frames = sim.maxFrames;
+        rq.min_fec = sim.fec;
+        rq.result_file = sim.resultFile ? sim.resultFile : "";
+        rq.cli_output = cli_output != 0;
+        n = run_simulation(*ctx->eng, rq, results, totals, stopFlag);
+    });
+    return rc == 0 ? n : -1;
+}
+
+} // extern "C"

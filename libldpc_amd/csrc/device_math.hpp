@@ -1,0 +1,85 @@
+// device_math.hpp — scalar building blocks shared by the HIP kernels.
+//
+// Everything here restates reference arithmetic so that results are bit-identical to the CPU
+// oracle built with ORC_MATH_DET (exp/log from detmath.h, everything else IEEE-754 binary64 in
+// the reference's own operation order).  Compile with -ffp-contract=off.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "detmath.h"
+
+namespace ldpc_amd
+{
+
+// decoder.h:7-10 — sign(x) = 1 - 2*signbit(x)
+__device__ __forceinline__ int sgn(double x) { return 1 - 2 * static_cast<int>(__builtin_signbit(x) != 0); }
+
+// std::min(a, b) == (b < a) ? b : a
+__device__ __forceinline__ double std_min(double a, double b) { return (b < a) ? b : a; }
+
+// decoder.h:17-20
+__device__ __forceinline__ double box_minsum(double x, double y)
+{
+    return static_cast<double>(sgn(x) * sgn(y)) * std_min(__builtin_fabs(x), __builtin_fabs(y));
+}
+
+// decoder.h:12-15 with exp/log from detmath.h
+__device__ __forceinline__ double box_jacobian(double x, double y)
+{
+    double m = static_cast<double>(sgn(x) * sgn(y)) * std_min(__builtin_fabs(x), __builtin_fabs(y));
+    double num = 1 + dm_exp(-__builtin_fabs(x + y));
+    double den = 1 + dm_exp(-__builtin_fabs(x - y));
+    return m + dm_log(num / den);
+}
+
+template <bool MINSUM>
+__device__ __forceinline__ double boxplus(double x, double y)
+{
+    if constexpr (MINSUM)
+        return box_minsum(x, y);
+    else
+        return box_jacobian(x, y);
+}
+
+// libstdc++ generate_canonical<double,53>(mt19937_64): one draw, double(u64)/2^64, clamped below 1
+__device__ __forceinline__ double canonical(uint64_t w)
+{
+    double r = static_cast<double>(w) * 0x1p-64;
+    return (r >= 1.0) ? 0x1.fffffffffffffp-1 : r;
+}
+
+// libstdc++ normal_distribution polar step on one trial (u1, u2): accepted iff 0 < r2 <= 1
+struct PolarTrial
+{
+    double x, y, r2;
+    __device__ __forceinline__ bool accepted() const { return !(r2 > 1.0 || r2 == 0.0); }
+};
+
+__device__ __forceinline__ PolarTrial polar_trial(uint64_t u1, uint64_t u2)
+{
+    PolarTrial t;
+    t.x = 2.0 * canonical(u1) - 1.0;
+    t.y = 2.0 * canonical(u2) - 1.0;
+    t.r2 = t.x * t.x + t.y * t.y;
+    return t;
+}
+
+// mt19937_64 tempering (u=29,d=0x5555..., s=17,b=0x71D67FFFEDA60000, t=37,c=0xFFF7EEE000000000, l=43)
+__device__ __forceinline__ uint64_t mt_temper(uint64_t z)
+{
+    z ^= (z >> 29) & 0x5555555555555555ull;
+    z ^= (z << 17) & 0x71D67FFFEDA60000ull;
+    z ^= (z << 37) & 0xFFF7EEE000000000ull;
+    z ^= (z >> 43);
+    return z;
+}
+
+// mt19937_64 twist: new x[k] = x[k+156] ^ ((upper(x[k]) | lower(x[k+1])) >> 1) ^ (odd ? A : 0)
+__device__ __forceinline__ uint64_t mt_twist(uint64_t xk, uint64_t xk1, uint64_t xm)
+{
+    uint64_t y = (xk & 0xFFFFFFFF80000000ull) | (xk1 & 0x7FFFFFFFull);
+    return xm ^ (y >> 1) ^ ((y & 1) ? 0xB5026F5AA96619E9ull : 0ull);
+}
+
+} // namespace ldpc_amd

@@ -1,0 +1,473 @@
+// engine.cpp — see engine.hpp.  Compiled by hipcc (host code using the HIP runtime API).
+#include "engine.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+
+namespace ldpc_amd
+{
+
+std::string hip_error_string(int err) { return hipGetErrorString(static_cast<hipError_t>(err)); }
+
+namespace
+{
+void check(hipError_t e, const char *what)
+{
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+void check(int e, const char *what) { check(static_cast<hipError_t>(e), what); }
+
+bool is_device_ptr(const void *p)
+{
+    if (!p)
+        return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess)
+    {
+        (void)hipGetLastError(); // plain host memory: clear the sticky error
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// routes an output either straight to the caller's device pointer or through a staging buffer
+struct OutStage
+{
+    struct Item
+    {
+        void *host, *dev;
+        size_t bytes;
+    };
+    std::vector<Item> items;
+    template <typename T>
+    T *route(T *user, DeviceBuffer &stage, size_t bytes)
+    {
+        if (!user)
+            return nullptr;
+        if (is_device_ptr(user))
+            return user;
+        void *d = stage.reserve(bytes);
+        items.push_back({user, d, bytes});
+        return static_cast<T *>(d);
+    }
+    void flush(hipStream_t s)
+    {
+        for (auto &i : items)
+            check(hipMemcpyAsync(i.host, i.dev, i.bytes, hipMemcpyDeviceToHost, s), "copy out");
+        if (!items.empty())
+            check(hipStreamSynchronize(s), "sync");
+        items.clear();
+    }
+};
+
+// t^(J*2^m) mod phi, computed lazily once per process
+const Gf2Poly &jump_poly(unsigned m)
+{
+    static std::mutex mu;
+    static std::vector<Gf2Poly> polys;
+    std::lock_guard<std::mutex> lk(mu);
+    if (mt64_charpoly().empty())
+        throw std::runtime_error("mt19937_64 characteristic polynomial has unexpected degree");
+    while (polys.size() <= m)
+    {
+        if (polys.empty())
+            polys.push_back(mt64_pow_t(MtStream::kChunkWords));
+        else
+            polys.push_back(gf2_mulmod(polys.back(), polys.back()));
+    }
+    return polys[m];
+}
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+DeviceBuffer::~DeviceBuffer()
+{
+    if (ptr_)
+        (void)hipFree(ptr_);
+}
+
+void *DeviceBuffer::reserve(size_t bytes)
+{
+    if (bytes > size_)
+    {
+        if (ptr_)
+            check(hipFree(ptr_), "hipFree");
+        ptr_ = nullptr;
+        size_t want = std::max(bytes, size_ + size_ / 2);
+        check(hipMalloc(&ptr_, want), "hipMalloc");
+        size_ = want;
+    }
+    return ptr_;
+}
+
+// ---------------------------------------------------------------------------------------------
+void MtStream::reset(uint64_t seed)
+{
+    if (valid_ && seed == seed_)
+        return; // chunk states depend on the seed only; keep them
+    seed_ = seed;
+    valid_ = false;
+}
+
+void MtStream::ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t row = sizeof(uint64_t) * kMtWords;
+    uint64_t *st = static_cast<uint64_t *>(states_.reserve(row * (kStateCap + 1)));
+    if (c_hi - c_lo > kStateCap)
+        throw std::runtime_error("mt19937_64 stream request exceeds the chunk-state table");
+    if (!valid_ || c_lo < base_)
+    {
+        uint64_t w0[kMtWords];
+        mt64_window0(seed_, w0);
+        check(hipMemcpyAsync(st, w0, row, hipMemcpyHostToDevice, s), "upload window0");
+        check(hipStreamSynchronize(s), "sync"); // w0 is a stack buffer
+        base_ = 0;
+        ready_ = 1;
+        pow_ready_ = 1;
+        valid_ = true;
+    }
+    auto rebase = [&](uint64_t c) {
+        const uint64_t r = c - base_;
+        check(hipMemcpyAsync(st, st + r * kMtWords, row, hipMemcpyDeviceToDevice, s), "rebase");
+        base_ = c;
+        ready_ = 1;
+        pow_ready_ = 1;
+    };
+    for (;;)
+    {
+        const uint64_t need = c_hi - base_;
+        if (need <= ready_)
+            return;
+        if (need > kStateCap)
+        {
+            if (c_lo - base_ < ready_)
+            {
+                rebase(c_lo);
+                continue;
+            }
+            if (pow_ready_ >= kStateCap) // far seek: stride forward by the table length
+            {
+                rebase(base_ + ready_ - 1);
+                continue;
+            }
+        }
+        // extend by doubling: rows [pow, 2*pow) = jump_{J*pow}(rows [0, pow))
+        unsigned m = 0;
+        while ((1u << m) < pow_ready_)
+            ++m;
+        const Gf2Poly &g = jump_poly(m);
+        uint64_t *pd = static_cast<uint64_t *>(poly_.reserve(row));
+        check(hipMemcpyAsync(pd, g.data(), row, hipMemcpyHostToDevice, s), "upload poly");
+        uint64_t *scr = static_cast<uint64_t *>(
+            scratch_.reserve(sizeof(uint64_t) * static_cast<size_t>(kJumpScratchWords) * pow_ready_));
+        check(launch_mt_jump(st, st + static_cast<size_t>(pow_ready_) * kMtWords, pd, scr, pow_ready_, s), "mt_jump");
+        check(hipStreamSynchronize(s), "sync"); // poly_ is reused by the next round
+        pow_ready_ *= 2;
+        ready_ = std::max(ready_, pow_ready_);
+    }
+}
+
+const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (count == 0)
+        count = 1;
+    const uint64_t c_lo = first / kChunkWords;
+    const uint64_t c_hi = (first + count + kChunkWords - 1) / kChunkWords;
+    ensure_states(c_lo, c_hi, stream);
+    const uint32_t n = static_cast<uint32_t>(c_hi - c_lo);
+    uint64_t *st = static_cast<uint64_t *>(states_.get());
+    uint64_t *raw = static_cast<uint64_t *>(raw_.reserve(sizeof(uint64_t) * kChunkWords * n));
+    uint64_t *next_last = st + (c_hi - base_) * kMtWords;
+    check(launch_mt_generate(st + (c_lo - base_) * kMtWords, next_last, raw, n, static_cast<uint32_t>(kChunkWords), s),
+          "mt_generate");
+    if (c_hi - base_ == ready_ && ready_ <= kStateCap)
+        ++ready_; // the state that follows the last generated chunk comes for free
+    return raw + (first - c_lo * kChunkWords);
+}
+
+// ---------------------------------------------------------------------------------------------
+Engine::Engine(const std::string &pc_file, const std::string &gen_file, int device) : device_(device)
+{
+    code_ = std::make_unique<LdpcCode>(pc_file, gen_file);
+    if (code_->min_cn_degree() < 2)
+        throw std::runtime_error("check nodes of degree < 2 are not supported (undefined in the reference decoder)");
+    plan_ = build_plan(*code_);
+}
+
+Engine::~Engine()
+{
+    for (void *p : owned_)
+        (void)hipFree(p);
+    for (void *e : ev_)
+        if (e)
+            (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+}
+
+void Engine::set_profiling(bool on)
+{
+    profiling_ = on;
+    if (on)
+        for (auto &e : ev_)
+            if (!e)
+            {
+                hipEvent_t ev;
+                check(hipEventCreate(&ev), "hipEventCreate");
+                e = ev;
+            }
+}
+
+float Engine::last_ms(int which)
+{
+    if (!ev_[0])
+        return 0.f;
+    hipEvent_t a = static_cast<hipEvent_t>(ev_[which ? 2 : 0]), b = static_cast<hipEvent_t>(ev_[which ? 3 : 1]);
+    if (hipEventSynchronize(b) != hipSuccess)
+        return 0.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return 0.f;
+    }
+    return ms;
+}
+
+void Engine::upload_plan()
+{
+    if (dev_.cn_blocks)
+        return;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= device_)
+        throw std::runtime_error("no usable HIP device (MI355X required): " + std::string(hipGetErrorString(e)));
+    check(hipSetDevice(device_), "hipSetDevice");
+    auto up = [&](const void *src, size_t bytes) -> void * {
+        void *d = nullptr;
+        check(hipMalloc(&d, std::max<size_t>(bytes, 16)), "hipMalloc plan");
+        owned_.push_back(d);
+        if (bytes)
+            check(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice), "upload plan");
+        return d;
+    };
+    const Plan &p = plan_;
+    dev_.nc = p.nc, dev_.mc = p.mc, dev_.nnz = p.nnz, dev_.nct = p.nct;
+    dev_.n_cn_blocks = static_cast<int>(p.cn_blocks.size());
+    dev_.n_vn_blocks = static_cast<int>(p.vn_blocks.size());
+    dev_.cn_work_stride = p.cn_work_stride, dev_.vn_work_stride = p.vn_work_stride;
+#define UP(field, vec) dev_.field = static_cast<decltype(dev_.field)>(up(vec.data(), vec.size() * sizeof(vec[0])))
+    UP(cn_blocks, p.cn_blocks);
+    UP(vn_blocks, p.vn_blocks);
+    UP(vn_slot, p.vn_slot);
+    UP(cn_work, p.cn_work);
+    UP(vn_work, p.vn_work);
+    UP(col_rank, p.col_rank);
+    UP(rank_col, p.rank_col);
+    UP(tx_rank, p.tx_rank);
+    UP(rank_kind, p.rank_kind);
+    UP(rank_slot0, p.rank_slot0);
+    UP(bit_pos, code_->bit_pos);
+    UP(row_ptr, p.row_ptr);
+    UP(row_edge_col, p.row_edge_col);
+    UP(col_ptr, p.col_ptr);
+    UP(col_edge, p.col_edge);
+#undef UP
+    dev_.lds_bytes = static_cast<uint32_t>(p.lds_bytes);
+}
+
+void Engine::synchronize(void *stream) { check(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "sync"); }
+
+void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, uint64_t n, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nc = plan_.nc;
+    OutStage st;
+    a.plan = dev_;
+    a.iterations = p.iterations;
+    a.early_term = p.early_term;
+    a.n_frames = n;
+    a.iters = st.route(out.iters, stage_iters_, 4 * n);
+    a.bit_errors = st.route(out.bit_errors, stage_be_, 4 * n);
+    a.hard = st.route(out.hard, stage_hard_, n * nc);
+    a.llr_out = st.route(out.llr_out, stage_llr_out_, 8 * n * nc);
+    a.llr_in_dump = st.route(out.llr_in, stage_llr_in_, 8 * n * nc);
+    if (!plan_.lds_ok)
+        throw std::runtime_error("code does not fit the LDS-resident decoder and the HBM-resident decoder is not built yet");
+    if (profiling_)
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), s), "event");
+    check(launch_decode_lds(a, p.min_sum, s), "decode_lds");
+    if (profiling_)
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_[1]), s), "event");
+    if (out.codeword)
+    {
+        if (a.codeword)
+            check(hipMemcpyAsync(out.codeword, a.codeword, n * nc,
+                                 is_device_ptr(out.codeword) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s),
+                  "codeword out");
+        else if (is_device_ptr(out.codeword))
+            check(hipMemsetAsync(out.codeword, 0, n * nc, s), "codeword out");
+        else
+            std::memset(out.codeword, 0, n * nc);
+    }
+    st.flush(s);
+}
+
+void Engine::decode_llr(const DecParams &p, uint64_t n, const double *llr_in, const BatchOut &out, void *stream)
+{
+    if (n == 0)
+        return;
+    upload_plan();
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t bytes = 8 * n * static_cast<size_t>(plan_.nc);
+    DecodeArgs a{};
+    a.mode = kModeLlr;
+    if (is_device_ptr(llr_in))
+        a.llr_in = llr_in;
+    else
+    {
+        void *d = stage_in_.reserve(bytes);
+        check(hipMemcpyAsync(d, llr_in, bytes, hipMemcpyHostToDevice, s), "copy in");
+        a.llr_in = static_cast<const double *>(d);
+    }
+    run_decode(a, p, out, n, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+void Engine::stream_begin(int channel, uint64_t seed, double x)
+{
+    if (channel != kAwgn && channel != kBsc && channel != kBec)
+        throw std::runtime_error("No channel selected.");
+    chan_ = channel;
+    x_ = x;
+    frame_pos_ = 0;
+    pair_next_ = 0;
+    raw_next_ = 0;
+    noise_.reset(seed);
+    if (channel == kAwgn)
+    {
+        sigma2_ = std::pow(10, -x / 10); // channel.cpp:39
+        sigma_ = std::sqrt(sigma2_);
+    }
+    else
+        delta_ = std::log((1 - x) / x); // channel.cpp:139
+}
+
+uint64_t Engine::stream_raw_draws() const { return raw_next_; }
+
+// Locate the accepted polar pairs that supply the normals of frames [frame_pos_, frame_pos_+n).
+void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t nct = static_cast<uint64_t>(plan_.nct);
+    const uint64_t g0 = frame_pos_ * nct, g1 = g0 + n * nct; // normals [g0, g1)
+    const uint64_t q_hi = (g1 - 1) >> 1;
+    const uint64_t want = q_hi + 1 - pair_next_;
+    // pairs_[0] holds the carry pair (rank pair_next_-1), new pairs follow
+    uint64_t *pairs = static_cast<uint64_t *>(pairs_.reserve(16 * (want + 1)));
+    uint64_t *carry = static_cast<uint64_t *>(carry_.reserve(16));
+    if (pair_next_ > 0)
+        check(hipMemcpyAsync(pairs, carry, 16, hipMemcpyDeviceToDevice, s), "carry in");
+    ScanResult *res = static_cast<ScanResult *>(scan_result_.reserve(sizeof(ScanResult)));
+    uint64_t trials = static_cast<uint64_t>(want * 1.2732395447351628 + 8.0 * std::sqrt(static_cast<double>(want)) + 256);
+    ScanResult h{};
+    if (profiling_)
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_[2]), s), "event");
+    for (;;)
+    {
+        const uint64_t *raw = noise_.generate(raw_next_, 2 * trials, stream);
+        const uint32_t n_blocks = static_cast<uint32_t>((trials + kScanBlock - 1) / kScanBlock);
+        uint32_t *counts = static_cast<uint32_t *>(scan_counts_.reserve(4 * static_cast<size_t>(n_blocks)));
+        uint64_t *offs = static_cast<uint64_t *>(scan_offsets_.reserve(8 * static_cast<size_t>(n_blocks)));
+        check(launch_polar_scan(raw, trials, want, counts, offs, pairs + 2, res, s), "polar_scan");
+        check(hipMemcpyAsync(&h, res, sizeof h, hipMemcpyDeviceToHost, s), "scan result");
+        check(hipStreamSynchronize(s), "sync");
+        if (h.enough)
+            break;
+        trials += trials / 8 + 4096; // vanishingly rare: take a longer look at the same stream
+    }
+    if (profiling_)
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_[3]), s), "event");
+    check(hipMemcpyAsync(carry, pairs + 2 * want, 16, hipMemcpyDeviceToDevice, s), "carry out");
+    a.pairs = pairs;
+    a.pair_base = pair_next_ - 1; // wraps to 2^64-1 for the very first batch: q - pair_base == q + 1
+    a.normal_base = g0;
+    a.sigma = sigma_, a.sigma2 = sigma2_;
+    a.shorten_llr = 99999.9; // channel.cpp:83
+    pair_next_ += want;
+    raw_next_ += 2 * h.trials_used;
+}
+
+void Engine::stream_skip(uint64_t n_frames, void *stream)
+{
+    if (!chan_)
+        throw std::runtime_error("stream_begin() has not been called");
+    upload_plan();
+    const uint64_t nct = static_cast<uint64_t>(plan_.nct);
+    while (n_frames)
+    {
+        const uint64_t n = std::min<uint64_t>(n_frames, 1u << 17);
+        if (chan_ == kAwgn)
+        {
+            DecodeArgs a{};
+            awgn_prepare(n, a, stream);
+        }
+        else
+            raw_next_ += n * nct;
+        frame_pos_ += n;
+        n_frames -= n;
+    }
+}
+
+void Engine::stream_decode(const DecParams &p, uint64_t n_frames, const BatchOut &out, void *stream)
+{
+    if (!chan_)
+        throw std::runtime_error("stream_begin() has not been called");
+    if (n_frames == 0)
+        return;
+    upload_plan();
+    if (code_->has_G())
+        throw std::runtime_error("encoding with a generator matrix is not built yet");
+    const uint64_t nct = static_cast<uint64_t>(plan_.nct), nc = static_cast<uint64_t>(plan_.nc);
+    uint64_t done = 0;
+    while (done < n_frames)
+    {
+        const uint64_t n = std::min<uint64_t>(n_frames - done, 1u << 17);
+        BatchOut o = out;
+        if (o.iters) o.iters += done;
+        if (o.bit_errors) o.bit_errors += done;
+        if (o.hard) o.hard += done * nc;
+        if (o.llr_out) o.llr_out += done * nc;
+        if (o.llr_in) o.llr_in += done * nc;
+        if (o.codeword) o.codeword += done * nc;
+        DecodeArgs a{};
+        if (chan_ == kAwgn)
+        {
+            a.mode = kModeAwgn;
+            awgn_prepare(n, a, stream);
+            run_decode(a, p, o, n, stream);
+        }
+        else if (chan_ == kBsc)
+        {
+            a.mode = kModeBsc;
+            a.raw = noise_.generate(raw_next_, n * nct, stream);
+            a.eps = x_, a.delta = delta_;
+            a.shorten_llr = delta_; // channel.cpp:152
+            raw_next_ += n * nct;
+            run_decode(a, p, o, n, stream);
+        }
+        else
+            throw std::runtime_error("BEC decoder is not built yet");
+        frame_pos_ += n;
+        done += n;
+    }
+}
+
+} // namespace ldpc_amd

@@ -1,0 +1,140 @@
+// engine.hpp — host runtime around the HIP kernels: device tables, workspaces, the mt19937_64
+// stream engine and the batched channel+decode step.  One Engine per (code, GPU).
+//
+// This is the native replacement for the reference's per-thread `channel` objects
+// (src/sim/channel.h:7-252) driven frame by frame from ldpc_sim::start (src/sim/ldpcsim.cpp:158-188):
+// instead of five virtual calls per frame, one call decodes a batch of frames of the same stream.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "code.hpp"
+#include "kernels.hpp"
+#include "mt64.hpp"
+#include "plan.hpp"
+
+namespace ldpc_amd
+{
+
+enum ChannelType : int
+{
+    kAwgn = 1, // same numbering as the reference's channel_type enum (ldpcsim.h:15-20)
+    kBsc = 2,
+    kBec = 3
+};
+
+struct DecParams
+{
+    bool early_term = true;
+    uint32_t iterations = 50;
+    bool min_sum = false;
+};
+
+// Output buffers of a batch; device or host pointers, nullptr = not wanted.
+struct BatchOut
+{
+    uint32_t *iters = nullptr;      // [n]
+    uint32_t *bit_errors = nullptr; // [n]
+    uint8_t *hard = nullptr;        // [n][nc]
+    double *llr_out = nullptr;      // [n][nc] (BEC: symbol values widened to double)
+    double *llr_in = nullptr;       // [n][nc]
+    uint8_t *codeword = nullptr;    // [n][nc]
+};
+
+class DeviceBuffer
+{
+  public:
+    DeviceBuffer() = default;
+    ~DeviceBuffer();
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    void *reserve(size_t bytes); // grow-only
+    void *get() const { return ptr_; }
+    size_t size() const { return size_; }
+
+  private:
+    void *ptr_ = nullptr;
+    size_t size_ = 0;
+};
+
+// One mt19937_64(seed) stream: chunk start states by jump-ahead, raw words generated on demand.
+class MtStream
+{
+  public:
+    static constexpr uint64_t kChunkWords = 210 * kMtWords; // 65520
+    static constexpr uint32_t kStateCap = 8192;
+    void reset(uint64_t seed);
+    uint64_t seed() const { return seed_; }
+    // Generate raw outputs [first, first+count) of the stream; returns a device pointer to word `first`.
+    const uint64_t *generate(uint64_t first, uint64_t count, void *stream);
+
+  private:
+    void ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream);
+    uint64_t seed_ = 0;
+    bool valid_ = false;
+    uint64_t base_ = 0;   // chunk id of state row 0
+    uint32_t ready_ = 0;  // rows [0, ready_) hold chunk start states
+    uint32_t pow_ready_ = 0; // power-of-two prefix obtained by doubling
+    DeviceBuffer states_, scratch_, raw_, poly_;
+};
+
+class Engine
+{
+  public:
+    Engine(const std::string &pc_file, const std::string &gen_file, int device);
+    ~Engine();
+
+    const LdpcCode &code() const { return *code_; }
+    const Plan &plan() const { return plan_; }
+    int device() const { return device_; }
+    bool bec_deg1_compat = false;
+
+    // ---- decode given LLRs (C-ABI decode(), shared.cpp:47-65, batched) ----
+    void decode_llr(const DecParams &p, uint64_t n, const double *llr_in, const BatchOut &out, void *stream);
+
+    // ---- fused channel + decode on the reference's noise stream ----
+    // set_channel_param semantics (channel.cpp:37-42): the stream restarts at frame 0.
+    void stream_begin(int channel, uint64_t seed, double x);
+    void stream_skip(uint64_t n_frames, void *stream);
+    void stream_decode(const DecParams &p, uint64_t n_frames, const BatchOut &out, void *stream);
+    uint64_t stream_frame() const { return frame_pos_; }
+    uint64_t stream_raw_draws() const;
+
+    void synchronize(void *stream);
+
+    // kernel timing with HIP events on the launch stream (bench.py's roofline figure)
+    void set_profiling(bool on);
+    // elapsed ms of the last batch: which = 0 decode kernel, 1 noise-stream kernels (generate + scan)
+    float last_ms(int which);
+
+  private:
+    void upload_plan();
+    void run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, uint64_t n, void *stream);
+    void awgn_prepare(uint64_t n_frames, DecodeArgs &a, void *stream);
+
+    std::unique_ptr<LdpcCode> code_;
+    Plan plan_;
+    DevPlan dev_{};
+    int device_ = 0;
+    std::vector<void *> owned_;
+
+    // stream state
+    int chan_ = 0;
+    double x_ = 0, sigma2_ = 0, sigma_ = 0, delta_ = 0;
+    uint64_t frame_pos_ = 0;
+    uint64_t pair_next_ = 0; // accepted polar pairs located so far
+    uint64_t raw_next_ = 0;  // raw draws consumed so far (AWGN: where the next trial starts)
+    MtStream noise_;
+    DeviceBuffer pairs_, carry_, scan_counts_, scan_offsets_, scan_result_;
+    DeviceBuffer stage_in_, stage_iters_, stage_be_, stage_hard_, stage_llr_out_, stage_llr_in_, stage_cw_;
+    DeviceBuffer hbm_msg_, hbm_llr_, hbm_hard_;
+    bool profiling_ = false;
+    void *ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+std::string hip_error_string(int err);
+
+} // namespace ldpc_amd

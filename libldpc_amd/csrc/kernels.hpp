@@ -1,0 +1,138 @@
+// kernels.hpp — host-visible launch interface of the HIP kernels (kernels.hip).
+#pragma once
+
+#include <cstdint>
+
+#include "plan.hpp"
+
+namespace ldpc_amd
+{
+
+// Device copy of Plan: all pointers are device pointers owned by the engine.
+struct DevPlan
+{
+    int nc, mc, nnz, nct;
+    int n_cn_blocks, n_vn_blocks;
+    int cn_work_stride, vn_work_stride;
+    const CnBlock *cn_blocks;
+    const VnBlock *vn_blocks;
+    const uint16_t *vn_slot;
+    const uint16_t *cn_work;
+    const uint16_t *vn_work;
+    const uint16_t *col_rank;
+    const uint16_t *rank_col;
+    const uint16_t *tx_rank;
+    const uint8_t *rank_kind;
+    const uint16_t *rank_slot0;
+    const int *bit_pos; // [nct] transmitted index -> column
+    // HBM-resident decoder tables
+    const uint32_t *row_ptr, *row_edge_col, *col_ptr, *col_edge;
+    uint32_t lds_bytes;
+};
+
+enum ChannelMode : int
+{
+    kModeLlr = 0,  // LLRs given per frame (C-ABI decode, shared.cpp:47-65)
+    kModeAwgn = 1, // fused channel_awgn::simulate + calculate_llrs (channel.cpp:62-93)
+    kModeBsc = 2,  // fused channel_bsc (channel.cpp:129-162)
+};
+
+struct DecodeArgs
+{
+    DevPlan plan;
+    uint32_t iterations;
+    int early_term;
+    int mode;
+    uint64_t n_frames;
+    // kModeLlr
+    const double *llr_in; // [n_frames][nc], column order
+    // kModeAwgn: accepted polar pairs (raw 64-bit draws u1,u2) of the normal stream; pair q of the
+    // stream sits at pairs[2*(q - pair_base)], normal g = frame*nct + i comes from pair g>>1.
+    const uint64_t *pairs;
+    uint64_t pair_base;
+    uint64_t normal_base; // index of this batch's first normal in the stream
+    double sigma, sigma2; // sqrt(sigma2), sigma2 = 10^(-snr/10)
+    double shorten_llr;   // 99999.9 (AWGN) or delta (BSC)
+    // kModeBsc: raw draws, one per transmitted bit: raw[frame*nct + i]
+    const uint64_t *raw;
+    double eps, delta;
+    // transmitted codeword per frame [n_frames][nc] (nullptr = all-zero codeword)
+    const uint8_t *codeword;
+    // outputs (any may be nullptr)
+    uint32_t *iters;
+    uint32_t *bit_errors;
+    uint8_t *hard;        // [n_frames][nc]
+    double *llr_out;      // [n_frames][nc]
+    double *llr_in_dump;  // [n_frames][nc]
+};
+
+// BEC (u8 erasure alphabet, decoder.cpp:91-192 + channel.cpp:199-229)
+struct BecArgs
+{
+    DevPlan plan;
+    uint32_t iterations;
+    int early_term;
+    int deg1_compat; // 1: erased degree-1 VN emits 0 (what the reference's out-of-bounds read yields)
+    uint64_t n_frames;
+    const uint64_t *raw; // raw[frame*nct + i], nullptr when symbols are given
+    double eps;
+    const uint8_t *symbols;  // [n_frames][nc] channel LLR alphabet {0,1,'E'} (when raw == nullptr)
+    const uint8_t *codeword; // [n_frames][nc] or nullptr
+    uint32_t *iters;
+    uint32_t *bit_errors;
+    uint8_t *hard;
+    uint8_t *llr_out;
+    uint8_t *llr_in_dump;
+};
+
+// All launchers enqueue on `stream` (hipStream_t passed as void*) and return a hipError_t as int.
+int launch_decode_lds(const DecodeArgs &a, bool min_sum, void *stream);
+int launch_decode_hbm(const DecodeArgs &a, bool min_sum, double *msg_ws, double *llr_ws, uint8_t *hard_ws,
+                      void *stream);
+int launch_bec(const BecArgs &a, void *stream);
+size_t hbm_workspace_bytes(const DevPlan &p, uint64_t n_frames, int which);
+
+// ---- mt19937_64 on the device ----
+constexpr int kMtN = 312;
+// Generate chunk_words raw (tempered) outputs per chunk: chunk c starts from states[c*312..] and
+// writes out[c*chunk_words ..]; the state that follows the LAST chunk is written to next_last[0..312)
+// (may be null).
+int launch_mt_generate(const uint64_t *states, uint64_t *next_last, uint64_t *out, uint32_t n_chunks,
+                       uint32_t chunk_words, void *stream);
+// Jump: for task t, dst_states[t] = state advanced by the polynomial `poly` (19937 coefficient bits in
+// 312 words) applied to src_states[t]; scratch holds 20280 words per task.
+int launch_mt_jump(const uint64_t *src_states, uint64_t *dst_states, const uint64_t *poly, uint64_t *scratch,
+                   uint32_t n_tasks, void *stream);
+constexpr uint32_t kJumpScratchWords = 65 * 312;
+
+// Polar-method acceptance scan over trials (raw[2t], raw[2t+1]):
+//   pass 1: block_counts[b] = accepted trials in block b (kScanBlock trials per block)
+//   pass 2 (after an exclusive scan of block_counts): compact accepted pairs into pairs_out
+struct ScanResult
+{
+    uint64_t accepted;      // accepted trials among those scanned
+    uint64_t trials_used;   // trials consumed up to and including the one that supplied pair `want-1`
+    uint32_t enough;        // 1 if accepted >= want
+    uint32_t pad;
+};
+constexpr uint32_t kScanBlock = 2048;
+int launch_polar_scan(const uint64_t *raw, uint64_t n_trials, uint64_t want_pairs, uint32_t *block_counts,
+                      uint64_t *block_offsets, uint64_t *pairs_out, ScanResult *result, void *stream);
+
+// GF(2) encode u*G accumulated into the running codeword (channel.cpp:44-60):
+//   info bits come from raw draws info_raw[frame*kc + i] (bernoulli(0.5): u < 0.5)
+struct EncodeArgs
+{
+    int nc, kc;
+    const uint32_t *g_col_ptr; // [nc+1] CSC of G
+    const uint32_t *g_col_row; // [g_nnz]
+    const uint64_t *info_raw;  // [n_frames][kc]
+    const uint8_t *cw_prev;    // [nc] running codeword before this batch
+    uint8_t *codeword;         // [n_frames][nc] out: codeword of each frame
+    uint8_t *cw_last;          // [nc] out: codeword after the batch
+    uint8_t *info_bits;        // [n_frames][kc] scratch
+    uint64_t n_frames;
+};
+int launch_encode(const EncodeArgs &a, void *stream);
+
+} // namespace ldpc_amd

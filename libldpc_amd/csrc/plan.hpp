@@ -1,0 +1,76 @@
+// plan.hpp — device execution plan for a parity-check graph.
+//
+// The reference walks H through per-node neighbour vectors (sparse.h:77-79) one frame at a time.
+// The MI355X decoder keeps one frame's messages in LDS and gives every lane one node, so the graph
+// is re-laid-out once per code:
+//
+//   * check nodes are grouped by degree into blocks of <= 64 (one wave, uniform degree, no
+//     divergence); block b owns message slots [off, off + degree*count), slot(lane, j) =
+//     off + j*count + lane, so a wave's j-th load/store is one contiguous, bank-conflict-free run;
+//   * variable nodes are grouped the same way; VN lane `rank` reaches its edges (in the file order
+//     the reference sums them in, decoder.cpp:50-56) through a u16 slot table laid out
+//     [block][position][lane] so the index loads coalesce;
+//   * blocks are dealt to the workgroup's waves by longest-processing-time so that waves finish
+//     each half-iteration together.
+//
+// Message values, their summation order and the per-edge results are those of the reference;
+// only where they live changes.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "code.hpp"
+
+namespace ldpc_amd
+{
+
+constexpr int kWaveSize = 64;
+constexpr int kMaxLdsCnDegree = 8;  // widest check node the register-resident CN update is built for
+constexpr int kDecodeWaves = 4;     // waves per workgroup of the LDS-resident decoder
+
+struct CnBlock
+{
+    uint32_t off;    // first message slot
+    uint16_t count;  // check nodes in the block (<= 64)
+    uint16_t degree;
+};
+
+struct VnBlock
+{
+    uint32_t idx_off; // into vn_slot: [idx_off + p*count + lane]
+    uint16_t first;   // first VN rank
+    uint16_t count;
+    uint16_t degree;
+    uint16_t pad;
+};
+
+// Host-side plan (uploaded verbatim by the engine)
+struct Plan
+{
+    int nc = 0, mc = 0, nnz = 0, nct = 0;
+    int max_cn_degree = 0, max_vn_degree = 0;
+    std::vector<CnBlock> cn_blocks;
+    std::vector<VnBlock> vn_blocks;
+    std::vector<uint16_t> vn_slot;   // slot of the p-th edge (column file order) of each VN
+    std::vector<uint16_t> cn_work;   // [kDecodeWaves][cn_work_stride] block ids, 0xFFFF = none
+    std::vector<uint16_t> vn_work;   // [kDecodeWaves][vn_work_stride]
+    int cn_work_stride = 0, vn_work_stride = 0;
+    std::vector<uint16_t> col_rank;  // column -> VN rank
+    std::vector<uint16_t> rank_col;  // VN rank -> column
+    std::vector<uint16_t> tx_rank;   // transmitted index i -> rank of bit_pos[i]
+    std::vector<uint8_t> rank_kind;  // 0 transmitted, 1 punctured, 2 shortened
+    std::vector<uint16_t> rank_slot0; // slot of the VN's first edge, 0xFFFF for an isolated VN
+    std::vector<uint32_t> edge_slot; // file-order edge -> slot (tests / debugging)
+    std::vector<uint32_t> cn_rank_row; // slot-space CN order -> original row (tests)
+    size_t lds_bytes = 0;            // dynamic LDS the LDS-resident kernel needs per frame
+    bool lds_ok = false;             // fits the LDS-resident kernel's limits
+
+    // HBM-resident (large code) tables: plain CSR/CSC in file order
+    std::vector<uint32_t> row_ptr, row_edge_col;  // [mc+1], [nnz] column of each row edge (file order)
+    std::vector<uint32_t> col_ptr, col_edge;      // [nc+1], [nnz] row-major edge id of each column edge
+};
+
+Plan build_plan(const LdpcCode &code);
+
+} // namespace ldpc_amd

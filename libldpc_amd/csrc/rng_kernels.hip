@@ -1,0 +1,278 @@
+// rng_kernels.hip — the reference's noise source rebuilt for the GPU.
+//
+// The reference draws all channel noise from ONE sequential std::mt19937_64(seed) per thread
+// (src/sim/channel.cpp:5-15,37-42), through libstdc++'s normal_distribution (Marsaglia polar
+// method with rejection: a data-dependent number of draws per sample).  To keep frame f the f-th
+// frame of that very stream while decoding tens of thousands of frames per launch, the stream is
+// produced in three data-parallel steps:
+//
+//   mt_jump_kernel      start state of every chunk of the stream, by GF(2) jump-ahead
+//                       (state_{n+J} = g_J(T) state_n; evaluated as a sliding XOR of sequence
+//                       words selected by the coefficients of g_J = t^J mod charpoly),
+//   mt_generate_kernel  one wave per chunk regenerates its 312-word state in LDS and writes the
+//                       tempered 64-bit outputs, 512 B per store instruction,
+//   polar_*_kernel      evaluates the polar acceptance test of every trial in parallel,
+//                       prefix-sums the accept flags and compacts the accepted (u1,u2) pairs in
+//                       stream order, so that normal number g is element g&1 of pair g>>1.
+//
+// The arithmetic of the acceptance test is device_math.hpp::polar_trial — the same code the
+// decoder prologue uses to turn a pair into two normals.
+#include <hip/hip_runtime.h>
+
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+namespace ldpc_amd
+{
+
+namespace
+{
+
+// one in-place regeneration of the 312-word window by one wave (see the hazard analysis in DESIGN.md):
+// rounds of 64 consecutive k; every lane reads x[k], x[k+1], x[k+156] (mod 312) before any lane of the
+// round writes, and a round only overwrites its own k range.
+__device__ __forceinline__ void mt_regenerate(uint64_t *x, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+    {
+        int k = r * 64 + lane;
+        uint64_t v = 0;
+        if (k < kMtN)
+        {
+            int k1 = k + 1 == kMtN ? 0 : k + 1;
+            int km = k + 156 >= kMtN ? k + 156 - kMtN : k + 156;
+            v = mt_twist(x[k], x[k1], x[km]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (k < kMtN)
+            x[k] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(64) void mt_generate_kernel(const uint64_t *states, uint64_t *next_last,
+                                                         uint64_t *out, uint32_t chunk_words)
+{
+    __shared__ uint64_t x[kMtN];
+    const int lane = threadIdx.x;
+    const uint64_t c = blockIdx.x;
+    const uint64_t *s = states + c * kMtN;
+    for (int k = lane; k < kMtN; k += 64)
+        x[k] = s[k];
+    __builtin_amdgcn_wave_barrier();
+    uint64_t *o = out + c * chunk_words;
+    const uint32_t blocks = chunk_words / kMtN;
+    for (uint32_t b = 0; b < blocks; ++b)
+    {
+        for (int k = lane; k < kMtN; k += 64)
+            o[b * kMtN + k] = mt_temper(x[k]);
+        mt_regenerate(x, lane);
+    }
+    if (next_last && c + 1 == gridDim.x) // the window after the last chunk = start state of the next chunk
+        for (int k = lane; k < kMtN; k += 64)
+            next_last[k] = x[k];
+}
+
+// dst = window at position n+J given the window at n: word i of the new window is the XOR of the
+// sequence words w[k+i] over all k with coefficient g_k = 1 (k < 19937).
+constexpr int kJumpThreads = 320;
+__global__ __launch_bounds__(kJumpThreads) void mt_jump_kernel(const uint64_t *src, uint64_t *dst,
+                                                               const uint64_t *poly, uint64_t *scratch)
+{
+    __shared__ uint64_t x[kMtN];
+    const int tid = threadIdx.x;
+    const uint64_t t = blockIdx.x;
+    uint64_t *w = scratch + t * kJumpScratchWords;
+    if (tid < 64)
+    {
+        for (int k = tid; k < kMtN; k += 64)
+            x[k] = src[t * kMtN + k];
+        __builtin_amdgcn_wave_barrier();
+        for (int b = 0; b < 65; ++b)
+        {
+            for (int k = tid; k < kMtN; k += 64)
+                w[b * kMtN + k] = x[k];
+            mt_regenerate(x, tid);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid < kMtN)
+    {
+        uint64_t acc = 0;
+        for (int wi = 0; wi < kMtN; ++wi)
+        {
+            uint64_t g = poly[wi]; // uniform
+            const uint64_t *base = w + wi * 64 + tid;
+            while (g)
+            {
+                int b = __builtin_ctzll(g);
+                g &= g - 1;
+                acc ^= base[b];
+            }
+        }
+        dst[t * kMtN + tid] = acc;
+    }
+}
+
+// ---- polar acceptance scan -------------------------------------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanIters = kScanBlock / kScanThreads; // trials per thread
+
+__device__ __forceinline__ bool trial_accepted(const uint64_t *raw, uint64_t t, uint64_t n_trials)
+{
+    if (t >= n_trials)
+        return false;
+    const ulonglong2 u = *reinterpret_cast<const ulonglong2 *>(raw + 2 * t);
+    return polar_trial(u.x, u.y).accepted();
+}
+
+__global__ __launch_bounds__(kScanThreads) void polar_count_kernel(const uint64_t *raw, uint64_t n_trials,
+                                                                   uint32_t *block_counts)
+{
+    __shared__ int total;
+    if (threadIdx.x == 0)
+        total = 0;
+    __syncthreads();
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanBlock;
+    int cnt = 0;
+#pragma unroll
+    for (int it = 0; it < kScanIters; ++it)
+        cnt += trial_accepted(raw, base + it * kScanThreads + threadIdx.x, n_trials);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0)
+        atomicAdd(&total, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        block_counts[blockIdx.x] = static_cast<uint32_t>(total);
+}
+
+// single-workgroup exclusive scan of the block counts
+__global__ __launch_bounds__(1024) void polar_offsets_kernel(const uint32_t *block_counts, uint32_t n_blocks,
+                                                             uint64_t *block_offsets, uint64_t want,
+                                                             ScanResult *result)
+{
+    __shared__ uint64_t part[1024];
+    const int tid = threadIdx.x;
+    const uint32_t per = (n_blocks + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = min(lo + per, n_blocks);
+    uint64_t s = 0;
+    for (uint32_t b = lo; b < hi; ++b)
+        s += block_counts[b];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) // Hillis-Steele inclusive scan
+    {
+        uint64_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint64_t run = tid ? part[tid - 1] : 0;
+    for (uint32_t b = lo; b < hi; ++b)
+    {
+        block_offsets[b] = run;
+        run += block_counts[b];
+    }
+    if (tid == 1023)
+    {
+        result->accepted = part[1023];
+        result->enough = part[1023] >= want;
+        if (want == 0)
+            result->trials_used = 0;
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void polar_compact_kernel(const uint64_t *raw, uint64_t n_trials,
+                                                                     const uint64_t *block_offsets, uint64_t want,
+                                                                     uint64_t *pairs_out, ScanResult *result)
+{
+    __shared__ int wave_cnt[kScanIters][kScanThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t off = block_offsets[blockIdx.x];
+    if (off >= want) // nothing this block holds is needed
+        return;
+    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanBlock;
+    bool acc[kScanIters];
+    int before[kScanIters]; // accepted lanes below this one in its wave
+#pragma unroll
+    for (int it = 0; it < kScanIters; ++it)
+    {
+        acc[it] = trial_accepted(raw, base + it * kScanThreads + tid, n_trials);
+        unsigned long long m = __ballot(acc[it]);
+        before[it] = __popcll(m & ((1ull << lane) - 1));
+        if (lane == 0)
+            wave_cnt[it][wave] = __popcll(m);
+    }
+    __syncthreads();
+    // trials are ordered (it, wave, lane) = ascending trial index
+    int run = 0;
+#pragma unroll
+    for (int it = 0; it < kScanIters; ++it)
+    {
+#pragma unroll
+        for (int w = 0; w < kScanThreads / 64; ++w)
+        {
+            if (w == wave && acc[it])
+            {
+                uint64_t rank = off + run + before[it];
+                if (rank < want)
+                {
+                    uint64_t t = base + it * kScanThreads + tid;
+                    if (pairs_out)
+                    {
+                        const ulonglong2 u = *reinterpret_cast<const ulonglong2 *>(raw + 2 * t);
+                        *reinterpret_cast<ulonglong2 *>(pairs_out + 2 * rank) = u;
+                    }
+                    if (rank == want - 1)
+                        result->trials_used = t + 1;
+                }
+            }
+            run += wave_cnt[it][w];
+        }
+    }
+}
+
+} // namespace
+
+int launch_mt_generate(const uint64_t *states, uint64_t *next_last, uint64_t *out, uint32_t n_chunks,
+                       uint32_t chunk_words, void *stream)
+{
+    if (n_chunks == 0)
+        return hipSuccess;
+    if (chunk_words % kMtN != 0)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mt_generate_kernel, dim3(n_chunks), dim3(64), 0, static_cast<hipStream_t>(stream), states,
+                       next_last, out, chunk_words);
+    return hipGetLastError();
+}
+
+int launch_mt_jump(const uint64_t *src_states, uint64_t *dst_states, const uint64_t *poly, uint64_t *scratch,
+                   uint32_t n_tasks, void *stream)
+{
+    if (n_tasks == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(mt_jump_kernel, dim3(n_tasks), dim3(kJumpThreads), 0, static_cast<hipStream_t>(stream),
+                       src_states, dst_states, poly, scratch);
+    return hipGetLastError();
+}
+
+int launch_polar_scan(const uint64_t *raw, uint64_t n_trials, uint64_t want_pairs, uint32_t *block_counts,
+                      uint64_t *block_offsets, uint64_t *pairs_out, ScanResult *result, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t n_blocks = static_cast<uint32_t>((n_trials + kScanBlock - 1) / kScanBlock);
+    if (n_blocks == 0)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(polar_count_kernel, dim3(n_blocks), dim3(kScanThreads), 0, s, raw, n_trials, block_counts);
+    hipLaunchKernelGGL(polar_offsets_kernel, dim3(1), dim3(1024), 0, s, block_counts, n_blocks, block_offsets,
+                       want_pairs, result);
+    hipLaunchKernelGGL(polar_compact_kernel, dim3(n_blocks), dim3(kScanThreads), 0, s, raw, n_trials, block_offsets,
+                       want_pairs, pairs_out, result);
+    return hipGetLastError();
+}
+
+} // namespace ldpc_amd

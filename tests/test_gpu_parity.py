@@ -1,0 +1,170 @@
+"""GPU parity tests: the HIP path (through the C ABI of libldpc.so) against the CPU oracle and the
+committed reference fixtures.  Run on the MI355X box: python -m pytest tests -m gpu
+
+Parity definition:
+  * everything that involves no exp/log (min-sum decoding, BSC/BEC channels, iteration counts, syndrome,
+    hard decisions, bit-error counts) is bit-exact against the reference fixtures;
+  * sum-product and the AWGN noise use exp/log: against the oracle built with the SAME deterministic
+    exp/log (ORC_MATH_DET) every double is bit-identical; against the reference (glibc libm) LLRs agree
+    within 1e-5 (north_star tolerance) and hard decisions / iteration counts are identical on converged
+    frames.
+"""
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star: "LLRs within 1e-5"
+
+
+@pytest.fixture(scope="module")
+def dec():
+    import libldpc_amd
+    d = libldpc_amd.HipDecoder(orc.H_TXT)
+    assert d.lib.ldpc_hip_device_count() >= 1, "no GPU visible"
+    return d
+
+
+@pytest.fixture(scope="module")
+def ocode():
+    return orc.Code(orc.H_TXT)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_device_mt19937_64_matches_stream(dec):
+    ref = orc.mt64_stream(0, 200000)
+    got = dec.mt64(0, 0, 200000)  # crosses three 65520-word chunks: exercises the jump-ahead states
+    assert np.array_equal(ref, got)
+    for seed, first, n in [(5489, 9999, 1), (7, 65519, 3), (123456789, 131040 - 5, 700)]:
+        ref = orc.mt64_stream(seed, first + n)[first:]
+        assert np.array_equal(ref, dec.mt64(seed, first, n)), (seed, first, n)
+    # ISO C++ known answer: 10000th output of mt19937_64(5489)
+    assert int(dec.mt64(5489, 9999, 1)[0]) == 9981545732273789042
+
+
+def test_device_mt19937_64_far_seek(dec):
+    first = 40_000_000  # ~610 chunks ahead: states come from 10 doubling rounds
+    ref = orc.mt64_stream(42, first + 1000)[first:]
+    assert np.array_equal(ref, dec.mt64(42, first, 1000))
+
+
+# ------------------------------------------------------------------------------------------------
+def test_minsum_decode_bit_exact_vs_reference(dec, golden_frames):
+    name = "awgn_ms_m5"
+    llr = golden_frames[f"{name}/llr_in"]
+    r = dec.decode_batch(llr, decoding="BP_MS")
+    assert np.array_equal(r["iters"], golden_frames[f"{name}/iters"])
+    assert np.array_equal(r["hard"], golden_frames[f"{name}/hard"])
+    assert np.array_equal(r["llr_out"], golden_frames[f"{name}/llr_out"])  # doubles, bit for bit
+
+
+def test_minsum_fixed_iterations_bit_exact(dec, golden_frames):
+    name = "awgn_ms_m4_noearly_i7"
+    r = dec.decode_batch(golden_frames[f"{name}/llr_in"], early_term=False, iterations=7, decoding="BP_MS")
+    assert np.array_equal(r["iters"], golden_frames[f"{name}/iters"])
+    assert np.array_equal(r["hard"], golden_frames[f"{name}/hard"])
+    assert np.array_equal(r["llr_out"], golden_frames[f"{name}/llr_out"])
+
+
+def test_bp_decode_bit_exact_vs_det_oracle(dec, ocode, golden_frames):
+    for name, early in (("awgn_bp_m4", True), ("awgn_bp_m6_noearly", False), ("awgn_bp_m4_skip1216", True)):
+        llr = golden_frames[f"{name}/llr_in"]
+        r = dec.decode_batch(llr, early_term=early)
+        for f in range(llr.shape[0]):
+            it, out, hard = ocode.decode(llr[f], early_term=early, math=orc.MATH_DET)
+            assert r["iters"][f] == it, (name, f)
+            assert np.array_equal(r["hard"][f], hard), (name, f)
+            assert np.array_equal(r["llr_out"][f], out), (name, f)  # bit-identical doubles, also when not converged
+
+
+def test_bp_decode_vs_reference_tolerance(dec, golden_frames):
+    name = "awgn_bp_m4"
+    r = dec.decode_batch(golden_frames[f"{name}/llr_in"])
+    assert np.array_equal(r["iters"], golden_frames[f"{name}/iters"])
+    assert np.array_equal(r["hard"], golden_frames[f"{name}/hard"])
+    assert np.max(np.abs(r["llr_out"] - golden_frames[f"{name}/llr_out"])) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+def _stream(dec, chan, x, seed, skip, count, **kw):
+    dec.stream_begin(chan, seed, x)
+    if skip:
+        dec.stream_skip(skip)
+    return dec.stream_decode(count, want=("iters", "bit_errors", "hard", "llr_out", "llr_in"), **kw)
+
+
+def test_awgn_stream_bit_exact_vs_det_oracle(dec, ocode):
+    for x, seed, skip, count, ms in [(-4.0, 0, 0, 24, False), (-5.0, 3, 5, 16, True), (-4.5, 9, 1216, 4, False)]:
+        r = _stream(dec, "AWGN", x, seed, skip, count, decoding="BP_MS" if ms else "BP")
+        o = ocode.run_frames("AWGN", x, seed=seed, skip=skip, count=count, min_sum=ms, math=orc.MATH_DET)
+        for k in ("llr_in", "iters", "bit_errors", "hard", "llr_out"):
+            assert np.array_equal(r[k], o[k]), (x, seed, k)
+        assert dec.stream_raw_draws == o["raw_draws"]
+
+
+def test_awgn_stream_vs_reference(dec, golden_frames):
+    for name, x, seed, skip, ms in [("awgn_bp_m4", -4.0, 0, 0, False), ("awgn_ms_m5", -5.0, 0, 0, True),
+                                    ("awgn_bp_m4_skip1216", -4.0, 0, 1216, False)]:
+        n = golden_frames[f"{name}/iters"].shape[0]
+        r = _stream(dec, "AWGN", x, seed, skip, n, decoding="BP_MS" if ms else "BP")
+        assert np.max(np.abs(r["llr_in"] - golden_frames[f"{name}/llr_in"])) < 1e-9
+        conv = golden_frames[f"{name}/iters"] < 50
+        assert np.array_equal(r["iters"][conv], golden_frames[f"{name}/iters"][conv])
+        assert np.array_equal(r["hard"][conv], golden_frames[f"{name}/hard"][conv])
+        assert np.max(np.abs(r["llr_out"][conv] - golden_frames[f"{name}/llr_out"][conv])) < TOL
+        # frames the reference fails to decode also fail here (their LLRs are chaotic in the last ulp of
+        # the noise sample, so their wrong bits are compared against the same-math oracle instead)
+        assert np.array_equal(r["iters"], golden_frames[f"{name}/iters"])
+        assert np.array_equal(r["bit_errors"] > 0, golden_frames[f"{name}/bit_errors"] > 0)
+
+
+def test_bsc_stream_bit_exact_vs_reference(dec, golden_frames):
+    # BSC: one draw per bit, LLR = +-delta: no transcendental on the device => the LLR-in is bit-exact
+    # against the reference; min-sum decoding then is too.
+    r = _stream(dec, "BSC", 0.24, 0, 0, 6, decoding="BP")
+    assert np.array_equal(r["llr_in"], golden_frames["bsc_bp_024/llr_in"])
+    assert np.array_equal(r["iters"], golden_frames["bsc_bp_024/iters"])
+    assert np.array_equal(r["hard"], golden_frames["bsc_bp_024/hard"])
+    assert np.max(np.abs(r["llr_out"] - golden_frames["bsc_bp_024/llr_out"])) < TOL
+
+
+def test_bsc_minsum_vs_oracle(dec, ocode):
+    r = _stream(dec, "BSC", 0.28, 1, 3, 8, decoding="BP_MS")
+    o = ocode.run_frames("BSC", 0.28, seed=1, skip=3, count=8, min_sum=True)  # libm oracle == reference
+    for k in ("llr_in", "iters", "bit_errors", "hard", "llr_out"):
+        assert np.array_equal(r[k], o[k]), k
+
+
+def test_counters_2000_frames_vs_reference(dec, golden_counters):
+    """iteration count and bit errors of the first 2000 frames at -4 dB (two frame errors, first at 1216)."""
+    dec.stream_begin("AWGN", 0, -4.0)
+    r = dec.stream_decode(2000)
+    ref_it, ref_be = golden_counters["awgn_bp_m4/iters"], golden_counters["awgn_bp_m4/bit_errors"]
+    conv = ref_it < 50
+    assert np.array_equal(r["iters"][conv], ref_it[conv])
+    assert np.array_equal(r["bit_errors"][conv], ref_be[conv])
+    assert np.array_equal(np.flatnonzero(r["bit_errors"]), np.flatnonzero(ref_be))
+
+
+def test_minsum_counters_1000_frames(dec, golden_counters):
+    dec.stream_begin("AWGN", 0, -4.5)
+    r = dec.stream_decode(1000, decoding="BP_MS")
+    ref_it, ref_be = golden_counters["awgn_ms_m45/iters"], golden_counters["awgn_ms_m45/bit_errors"]
+    conv = ref_it < 50
+    assert np.array_equal(r["iters"][conv], ref_it[conv])
+    assert np.array_equal(r["bit_errors"][conv], ref_be[conv])
+    assert np.array_equal(r["bit_errors"] > 0, ref_be > 0)
+    # failing frames: same frames fail, and the bit-error totals agree to within a few percent
+    assert abs(int(r["bit_errors"].sum()) - int(ref_be.sum())) < 0.05 * int(ref_be.sum())
+
+
+def test_batch_split_is_invisible(dec):
+    """Frame f is the f-th frame of the stream however the batches are cut."""
+    dec.stream_begin("AWGN", 5, -4.2)
+    a = dec.stream_decode(300, decoding="BP_MS")
+    dec.stream_begin("AWGN", 5, -4.2)
+    parts = [dec.stream_decode(n, decoding="BP_MS") for n in (1, 7, 92, 200)]
+    assert np.array_equal(a["iters"], np.concatenate([p["iters"] for p in parts]))
+    assert np.array_equal(a["bit_errors"], np.concatenate([p["bit_errors"] for p in parts]))

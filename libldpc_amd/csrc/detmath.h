@@ -153,4 +153,98 @@ DM_FN double dm_log(double x)
     return DM_FMA(dk, DM_LN2_HI32, f - (hfsq - lo));
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * dm_boxplus — the sum-product box-plus of the reference (src/decoding/decoder.h:12-15)
+ *
+ *     jacobian(x,y) = sign(x) sign(y) min(|x|,|y|) + log( (1 + e^-|x+y|) / (1 + e^-|x-y|) )
+ *
+ * evaluated in the reference's own order (two exponentials, two additions, one IEEE division, one
+ * logarithm, one addition) with an exp/log pair specialised for this call site and written for the
+ * GPU's instruction mix: branch-free, no table for exp, a 64-entry {1/c, log c} table for log so that
+ * no second division is needed.
+ *   dm_boxplus_exp(t) = e^-t for t >= 0, relative error < 1.1 ulp; arguments beyond 700 are clamped
+ *                       (only 1 + e^-t is ever formed, and 1 + e^-700 == 1).
+ *   dm_boxplus_log(q) = log q for q in [1/2, 2], ABSOLUTE error < 1.5e-16 (q itself carries an absolute
+ *                       rounding error of 1.1e-16 from the division, in the reference too).
+ * Both are pure binary64 arithmetic with explicit fma: the CPU oracle (ORC_MATH_DET) and the HIP
+ * kernels produce identical bits.
+ * ------------------------------------------------------------------------------------------------ */
+#include "detmath_tables.h"
+
+#if defined(__HIPCC__)
+__device__ static const double dm_bpl_table_dev[2 << DM_BPL_NBITS] __attribute__((aligned(16))) = {DM_BPL_TABLE};
+#endif
+static const double dm_bpl_table_host[2 << DM_BPL_NBITS] __attribute__((aligned(16))) = {DM_BPL_TABLE};
+
+DM_FN double dm_boxplus_exp(double t)
+{
+    double x = -__builtin_fmin(t, 700.0);
+    double z = x * DM_INV_LN2;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double kd = __builtin_rint(z); /* v_rndne_f64: same value as the add/subtract form below */
+#else
+    double kd = (z + DM_RND_MAGIC) - DM_RND_MAGIC;
+#endif
+    double r = DM_FMA(kd, -DM_LN2_HI, x);
+    r = DM_FMA(kd, -DM_LN2_LO, r);
+    double g = DM_EXP_G9;
+    g = DM_FMA(g, r, DM_EXP_G8);
+    g = DM_FMA(g, r, DM_EXP_G7);
+    g = DM_FMA(g, r, DM_EXP_G6);
+    g = DM_FMA(g, r, DM_EXP_G5);
+    g = DM_FMA(g, r, DM_EXP_G4);
+    g = DM_FMA(g, r, DM_EXP_G3);
+    g = DM_FMA(g, r, DM_EXP_G2);
+    g = DM_FMA(g, r, DM_EXP_G1);
+    g = DM_FMA(g, r, DM_EXP_G0);
+    double r2 = r * r;
+    double s = DM_FMA(r2, g, r);
+    double p = 1.0 + s;
+    int k = (int)kd; /* -1010 <= k <= 0: the scaled result is a normal number */
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_ldexp(p, k); /* v_ldexp_f64: exact scaling, same value as the multiply below */
+#else
+    return p * dm_from_bits((uint64_t)(k + 1023) << 52);
+#endif
+}
+
+DM_FN double dm_boxplus_log(double q)
+{
+    uint64_t ix = dm_bits(q);
+    uint32_t hi = (uint32_t)(ix >> 32);
+    uint32_t tmp = hi - DM_BPL_OFF_HI; /* the low word of the offset is zero */
+    int32_t k = (int32_t)tmp >> 20;
+    uint32_t i = (tmp >> (20 - DM_BPL_NBITS)) & ((1u << DM_BPL_NBITS) - 1u);
+    uint32_t zhi = hi - (tmp & 0xFFF00000u);
+    double z = dm_from_bits(((uint64_t)zhi << 32) | (uint32_t)ix);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double2 tc = *reinterpret_cast<const double2 *>(dm_bpl_table_dev + 2 * i);
+    double invc = tc.x, logc = tc.y;
+#else
+    double invc = dm_bpl_table_host[2 * i], logc = dm_bpl_table_host[2 * i + 1];
+#endif
+    double r = DM_FMA(z, invc, -1.0);
+    double r2 = r * r;
+    double p = DM_BPL_P5;
+    p = DM_FMA(p, r, DM_BPL_P4);
+    p = DM_FMA(p, r, DM_BPL_P3);
+    p = DM_FMA(p, r, DM_BPL_P2);
+    p = DM_FMA(p, r, DM_BPL_P1);
+    p = DM_FMA(p, r, DM_BPL_P0);
+    double w = DM_FMA((double)k, DM_LN2_HI, logc);
+    double l = DM_FMA(r2, p, r);
+    return w + l;
+}
+
+DM_FN double dm_boxplus(double x, double y)
+{
+    double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    double mn = __builtin_fmin(ax, ay); /* == std::min(|x|, |y|) for every non-NaN pair */
+    uint64_t sgn = (dm_bits(x) ^ dm_bits(y)) & 0x8000000000000000ull;
+    double m = dm_from_bits(dm_bits(mn) | sgn); /* sign(x) sign(y) min: -0.0 when the signs differ and min is 0 */
+    double num = 1.0 + dm_boxplus_exp(__builtin_fabs(x + y));
+    double den = 1.0 + dm_boxplus_exp(__builtin_fabs(x - y));
+    return m + dm_boxplus_log(num / den);
+}
+
 #endif /* LDPC_AMD_DETMATH_H */

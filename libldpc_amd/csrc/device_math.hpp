@@ -24,14 +24,8 @@ __device__ __forceinline__ double box_minsum(double x, double y)
     return static_cast<double>(sgn(x) * sgn(y)) * std_min(__builtin_fabs(x), __builtin_fabs(y));
 }
 
-// decoder.h:12-15 with exp/log from detmath.h
-__device__ __forceinline__ double box_jacobian(double x, double y)
-{
-    double m = static_cast<double>(sgn(x) * sgn(y)) * std_min(__builtin_fabs(x), __builtin_fabs(y));
-    double num = 1 + dm_exp(-__builtin_fabs(x + y));
-    double den = 1 + dm_exp(-__builtin_fabs(x - y));
-    return m + dm_log(num / den);
-}
+// decoder.h:12-15 with the deterministic exp/log pair of detmath.h
+__device__ __forceinline__ double box_jacobian(double x, double y) { return dm_boxplus(x, y); }
 
 template <bool MINSUM>
 __device__ __forceinline__ double boxplus(double x, double y)

@@ -4,7 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -16,6 +19,21 @@ std::string hip_error_string(int err) { return hipGetErrorString(static_cast<hip
 
 namespace
 {
+// LDPC_AMD_TRACE=1: host wall-clock of the phases of a batch, on stderr
+struct PhaseTrace
+{
+    bool on = std::getenv("LDPC_AMD_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char *what)
+    {
+        if (!on)
+            return;
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[ldpc_amd] %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 void check(hipError_t e, const char *what)
 {
     if (e != hipSuccess)
@@ -163,16 +181,34 @@ void MtStream::ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream)
         unsigned m = 0;
         while ((1u << m) < pow_ready_)
             ++m;
-        const Gf2Poly &g = jump_poly(m);
-        uint64_t *pd = static_cast<uint64_t *>(poly_.reserve(row));
-        check(hipMemcpyAsync(pd, g.data(), row, hipMemcpyHostToDevice, s), "upload poly");
-        uint64_t *scr = static_cast<uint64_t *>(
-            scratch_.reserve(sizeof(uint64_t) * static_cast<size_t>(kJumpScratchWords) * pow_ready_));
-        check(launch_mt_jump(st, st + static_cast<size_t>(pow_ready_) * kMtWords, pd, scr, pow_ready_, s), "mt_jump");
-        check(hipStreamSynchronize(s), "sync"); // poly_ is reused by the next round
+        check(launch_mt_jump(st, st + static_cast<size_t>(pow_ready_) * kMtWords, device_poly(m, stream), pow_ready_, s),
+              "mt_jump");
         pow_ready_ *= 2;
         ready_ = std::max(ready_, pow_ready_);
     }
+}
+
+// device copy of t^(J*2^m) mod phi, uploaded once per stream object
+const uint64_t *MtStream::device_poly(unsigned m, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    constexpr unsigned kMaxPolys = 16;
+    if (m >= kMaxPolys)
+        throw std::runtime_error("mt19937_64 jump distance out of range");
+    const size_t bytes = sizeof(uint64_t) * kJumpPolyWords;
+    uint64_t *base = static_cast<uint64_t *>(poly_.reserve(bytes * kMaxPolys));
+    while (polys_uploaded_ <= m)
+    {
+        const Gf2Poly &g = jump_poly(polys_uploaded_);
+        std::vector<uint64_t> padded(kJumpPolyWords, 0);
+        std::copy(g.begin(), g.begin() + kMtWords, padded.begin());
+        check(hipMemcpyAsync(base + static_cast<size_t>(polys_uploaded_) * kJumpPolyWords, padded.data(), bytes,
+                             hipMemcpyHostToDevice, s),
+              "upload poly");
+        check(hipStreamSynchronize(s), "sync"); // `padded` is a local buffer
+        ++polys_uploaded_;
+    }
+    return base + static_cast<size_t>(m) * kJumpPolyWords;
 }
 
 const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream)
@@ -378,17 +414,20 @@ void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream)
     ScanResult *res = static_cast<ScanResult *>(scan_result_.reserve(sizeof(ScanResult)));
     uint64_t trials = static_cast<uint64_t>(want * 1.2732395447351628 + 8.0 * std::sqrt(static_cast<double>(want)) + 256);
     ScanResult h{};
+    PhaseTrace tr;
     if (profiling_)
         check(hipEventRecord(static_cast<hipEvent_t>(ev_[2]), s), "event");
     for (;;)
     {
         const uint64_t *raw = noise_.generate(raw_next_, 2 * trials, stream);
+        tr.mark("generate(enqueue)");
         const uint32_t n_blocks = static_cast<uint32_t>((trials + kScanBlock - 1) / kScanBlock);
         uint32_t *counts = static_cast<uint32_t *>(scan_counts_.reserve(4 * static_cast<size_t>(n_blocks)));
         uint64_t *offs = static_cast<uint64_t *>(scan_offsets_.reserve(8 * static_cast<size_t>(n_blocks)));
         check(launch_polar_scan(raw, trials, want, counts, offs, pairs + 2, res, s), "polar_scan");
         check(hipMemcpyAsync(&h, res, sizeof h, hipMemcpyDeviceToHost, s), "scan result");
         check(hipStreamSynchronize(s), "sync");
+        tr.mark("scan+sync");
         if (h.enough)
             break;
         trials += trials / 8 + 4096; // vanishingly rare: take a longer look at the same stream
@@ -451,8 +490,11 @@ void Engine::stream_decode(const DecParams &p, uint64_t n_frames, const BatchOut
         if (chan_ == kAwgn)
         {
             a.mode = kModeAwgn;
+            PhaseTrace tr;
             awgn_prepare(n, a, stream);
+            tr.mark("awgn_prepare");
             run_decode(a, p, o, n, stream);
+            tr.mark("run_decode(enq)");
         }
         else if (chan_ == kBsc)
         {

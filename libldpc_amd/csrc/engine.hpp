@@ -73,12 +73,14 @@ class MtStream
 
   private:
     void ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream);
+    const uint64_t *device_poly(unsigned m, void *stream);
     uint64_t seed_ = 0;
     bool valid_ = false;
     uint64_t base_ = 0;   // chunk id of state row 0
     uint32_t ready_ = 0;  // rows [0, ready_) hold chunk start states
     uint32_t pow_ready_ = 0; // power-of-two prefix obtained by doubling
-    DeviceBuffer states_, scratch_, raw_, poly_;
+    unsigned polys_uploaded_ = 0;
+    DeviceBuffer states_, raw_, poly_;
 };
 
 class Engine

@@ -99,11 +99,11 @@ constexpr int kMtN = 312;
 // (may be null).
 int launch_mt_generate(const uint64_t *states, uint64_t *next_last, uint64_t *out, uint32_t n_chunks,
                        uint32_t chunk_words, void *stream);
-// Jump: for task t, dst_states[t] = state advanced by the polynomial `poly` (19937 coefficient bits in
-// 312 words) applied to src_states[t]; scratch holds 20280 words per task.
-int launch_mt_jump(const uint64_t *src_states, uint64_t *dst_states, const uint64_t *poly, uint64_t *scratch,
-                   uint32_t n_tasks, void *stream);
-constexpr uint32_t kJumpScratchWords = 65 * 312;
+// Jump: for task t, dst_states[t] = src_states[t] advanced by the polynomial `poly` (19937 coefficient
+// bits, kJumpPolyWords words: 312 + zero padding).
+int launch_mt_jump(const uint64_t *src_states, uint64_t *dst_states, const uint64_t *poly, uint32_t n_tasks,
+                   void *stream);
+constexpr uint32_t kJumpPolyWords = 320;
 
 // Polar-method acceptance scan over trials (raw[2t], raw[2t+1]):
 //   pass 1: block_counts[b] = accepted trials in block b (kScanBlock trials per block)

@@ -76,44 +76,82 @@ __global__ __launch_bounds__(64) void mt_generate_kernel(const uint64_t *states,
 
 // dst = window at position n+J given the window at n: word i of the new window is the XOR of the
 // sequence words w[k+i] over all k with coefficient g_k = 1 (k < 19937).
+//
+// The sequence is never written to memory: the workgroup keeps two consecutive 312-word blocks of it
+// in LDS (ring[0..311] = block b, ring[312..623] = block b+1).  In stage b thread i owns output word i
+// and consumes the taps k in [312 b, 312 b + 312): w[k+i] = ring[k - 312 b + i], consecutive lanes read
+// consecutive words.  Wave 0 then regenerates the next block and the ring advances.  The taps of a stage
+// are taken eight at a time: eight independent LDS reads in flight, then eight XORs predicated on
+// wave-uniform coefficient bits.
 constexpr int kJumpThreads = 320;
+constexpr int kJumpStages = 64;      // 64 * 312 = 19968 >= 19937 taps
+constexpr int kPolyWords = 320;      // 312 coefficient words + zero padding read by the last stage
+
 __global__ __launch_bounds__(kJumpThreads) void mt_jump_kernel(const uint64_t *src, uint64_t *dst,
-                                                               const uint64_t *poly, uint64_t *scratch)
+                                                               const uint64_t *poly)
 {
-    __shared__ uint64_t x[kMtN];
+    __shared__ uint64_t x[kMtN];        // generator state = newest block
+    __shared__ uint64_t ring[2 * kMtN];
+    __shared__ uint64_t g[kPolyWords];
     const int tid = threadIdx.x;
     const uint64_t t = blockIdx.x;
-    uint64_t *w = scratch + t * kJumpScratchWords;
-    if (tid < 64)
-    {
-        for (int k = tid; k < kMtN; k += 64)
-            x[k] = src[t * kMtN + k];
-        __builtin_amdgcn_wave_barrier();
-        for (int b = 0; b < 65; ++b)
-        {
-            for (int k = tid; k < kMtN; k += 64)
-                w[b * kMtN + k] = x[k];
-            mt_regenerate(x, tid);
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
+    for (int k = tid; k < kPolyWords; k += kJumpThreads)
+        g[k] = poly[k];
     if (tid < kMtN)
     {
-        uint64_t acc = 0;
-        for (int wi = 0; wi < kMtN; ++wi)
+        uint64_t v = src[t * kMtN + tid];
+        x[tid] = v;
+        ring[tid] = v;
+    }
+    __syncthreads();
+    if (tid < 64)
+        mt_regenerate(x, tid);
+    __syncthreads();
+    if (tid < kMtN)
+        ring[kMtN + tid] = x[tid];
+    __syncthreads();
+
+    uint64_t acc = 0;
+    for (int b = 0; b < kJumpStages; ++b)
+    {
+        if (tid < kMtN)
         {
-            uint64_t g = poly[wi]; // uniform
-            const uint64_t *base = w + wi * 64 + tid;
-            while (g)
+            const int k0 = b * kMtN;
+            for (int kk = 0; kk < kMtN; kk += 8)
             {
-                int b = __builtin_ctzll(g);
-                g &= g - 1;
-                acc ^= base[b];
+                // eight coefficient bits starting at k0 + kk (wave-uniform)
+                const int k = k0 + kk;
+                const int w = k >> 6, sh = k & 63;
+                uint64_t lo = g[w] >> sh;
+                uint64_t hi = sh ? (g[w + 1] << (64 - sh)) : 0;
+                uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(lo | hi))) & 0xFFu;
+                if (bits == 0)
+                    continue;
+                uint64_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = ring[kk + j + tid];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (bits >> j & 1)
+                        acc ^= v[j];
             }
         }
-        dst[t * kMtN + tid] = acc;
+        __syncthreads();
+        // advance: block b+1 becomes the low half, wave 0 produces block b+2
+        if (tid < 64)
+            mt_regenerate(x, tid);
+        uint64_t up = tid < kMtN ? ring[kMtN + tid] : 0;
+        __syncthreads();
+        if (tid < kMtN)
+        {
+            ring[tid] = up;
+            ring[kMtN + tid] = x[tid];
+        }
+        __syncthreads();
     }
+    if (tid < kMtN)
+        dst[t * kMtN + tid] = acc;
 }
 
 // ---- polar acceptance scan -------------------------------------------------------------------
@@ -250,13 +288,13 @@ int launch_mt_generate(const uint64_t *states, uint64_t *next_last, uint64_t *ou
     return hipGetLastError();
 }
 
-int launch_mt_jump(const uint64_t *src_states, uint64_t *dst_states, const uint64_t *poly, uint64_t *scratch,
-                   uint32_t n_tasks, void *stream)
+int launch_mt_jump(const uint64_t *src_states, uint64_t *dst_states, const uint64_t *poly, uint32_t n_tasks,
+                   void *stream)
 {
     if (n_tasks == 0)
         return hipSuccess;
     hipLaunchKernelGGL(mt_jump_kernel, dim3(n_tasks), dim3(kJumpThreads), 0, static_cast<hipStream_t>(stream),
-                       src_states, dst_states, poly, scratch);
+                       src_states, dst_states, poly);
     return hipGetLastError();
 }
 

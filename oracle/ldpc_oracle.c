@@ -325,11 +325,8 @@ static double jacobian_libm(double x, double y)
     return sgn(x) * sgn(y) * stdmin(fabs(x), fabs(y)) +
            log((1 + exp(-fabs(x + y))) / (1 + exp(-fabs(x - y))));
 }
-static double jacobian_det(double x, double y)
-{
-    return sgn(x) * sgn(y) * stdmin(fabs(x), fabs(y)) +
-           dm_log((1 + dm_exp(-fabs(x + y))) / (1 + dm_exp(-fabs(x - y))));
-}
+/* same expression with the deterministic exp/log pair of detmath.h (dm_boxplus spells it out) */
+static double jacobian_det(double x, double y) { return dm_boxplus(x, y); }
 /* decoder.h:17-20 */
 static double minsum(double x, double y) { return sgn(x) * sgn(y) * stdmin(fabs(x), fabs(y)); }
 

@@ -105,6 +105,8 @@ ldpc_hip_ctx *ldpc_hip_create(const char *pcFile, const char *genFile, int devic
 void ldpc_hip_destroy(ldpc_hip_ctx *ctx);
 /* info[0..9] = nc, mc, nnz, nct, mct, kct, kc, max_degree, lds_resident(0/1), lds_bytes_per_frame */
 void ldpc_hip_code_info(const ldpc_hip_ctx *ctx, int64_t info[10]);
+/* the text block the reference CLI prints for a code (ldpc.cpp:111-130); owned by the context */
+const char *ldpc_hip_describe(ldpc_hip_ctx *ctx);
 /* BEC: 1 = reproduce the reference's out-of-bounds read for erased degree-1 variable nodes
    (they emit 0); 0 (default) = defined semantics, they emit an erasure */
 void ldpc_hip_set_bec_compat(ldpc_hip_ctx *ctx, int compat);

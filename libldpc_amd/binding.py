@@ -150,6 +150,7 @@ class HipDecoder:
         return bufs
 
     def stream_begin(self, channel, seed, x):
+        """Channel point x of mt19937_64(seed); also resets the encoder (a fresh channel object)."""
         ch = CHANNELS[channel] if isinstance(channel, str) else int(channel)
         self._check(self.lib.ldpc_hip_stream_begin(self.ctx, ch, int(seed), float(x)), "ldpc_hip_stream_begin")
 

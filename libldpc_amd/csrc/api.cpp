@@ -25,6 +25,7 @@ struct ldpc_hip_ctx
     std::unique_ptr<Engine> eng;
     MtStream aux;
     DeviceBuffer aux_out;
+    std::string description;
 };
 
 namespace
@@ -235,6 +236,12 @@ void ldpc_hip_code_info(const ldpc_hip_ctx *ctx, int64_t info[10])
     info[9] = static_cast<int64_t>(p.lds_bytes);
 }
 
+const char *ldpc_hip_describe(ldpc_hip_ctx *ctx)
+{
+    ctx->description = ctx->eng->code().describe();
+    return ctx->description.c_str();
+}
+
 void ldpc_hip_set_bec_compat(ldpc_hip_ctx *ctx, int compat) { ctx->eng->bec_deg1_compat = compat != 0; }
 
 int ldpc_hip_decode_batch(ldpc_hip_ctx *ctx, decoder_param dec, uint64_t n, const double *llr_in,
@@ -245,7 +252,7 @@ int ldpc_hip_decode_batch(ldpc_hip_ctx *ctx, decoder_param dec, uint64_t n, cons
 
 int ldpc_hip_stream_begin(ldpc_hip_ctx *ctx, int channel, uint64_t seed, double x)
 {
-    return guarded([&] { ctx->eng->stream_begin(channel, seed, x); });
+    return guarded([&] { ctx->eng->stream_begin(channel, seed, x, true); });
 }
 
 int ldpc_hip_stream_skip(ldpc_hip_ctx *ctx, uint64_t n, void *hip_stream)

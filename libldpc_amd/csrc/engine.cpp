@@ -311,20 +311,31 @@ void Engine::upload_plan()
     UP(rank_kind, p.rank_kind);
     UP(rank_slot0, p.rank_slot0);
     UP(bit_pos, code_->bit_pos);
-    UP(row_ptr, p.row_ptr);
-    UP(row_edge_col, p.row_edge_col);
-    UP(col_ptr, p.col_ptr);
-    UP(col_edge, p.col_edge);
 #undef UP
+    if (code_->has_G())
+    {
+        std::vector<uint32_t> cp(code_->G.cptr.begin(), code_->G.cptr.end()), cr(code_->G.crow.begin(), code_->G.crow.end());
+        g_col_ptr_ = static_cast<const uint32_t *>(up(cp.data(), cp.size() * 4));
+        g_col_row_ = static_cast<const uint32_t *>(up(cr.data(), cr.size() * 4));
+    }
     dev_.lds_bytes = static_cast<uint32_t>(p.lds_bytes);
 }
 
 void Engine::synchronize(void *stream) { check(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "sync"); }
 
+// frames per launch: bounded so that the noise-stream buffers and the memory-resident workspace stay modest
+uint64_t Engine::max_sub_batch() const
+{
+    if (plan_.lds_ok)
+        return 1u << 17;
+    const uint64_t per_frame = 8ull * plan_.nnz + 8ull * plan_.nc + plan_.nnz;
+    return std::max<uint64_t>(1, std::min<uint64_t>(1u << 17, (8ull << 30) / per_frame));
+}
+
 void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, uint64_t n, void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t nc = plan_.nc;
+    const size_t nc = plan_.nc, nnz = plan_.nnz;
     OutStage st;
     a.plan = dev_;
     a.iterations = p.iterations;
@@ -335,11 +346,26 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
     a.hard = st.route(out.hard, stage_hard_, n * nc);
     a.llr_out = st.route(out.llr_out, stage_llr_out_, 8 * n * nc);
     a.llr_in_dump = st.route(out.llr_in, stage_llr_in_, 8 * n * nc);
-    if (!plan_.lds_ok)
-        throw std::runtime_error("code does not fit the LDS-resident decoder and the HBM-resident decoder is not built yet");
     if (profiling_)
         check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), s), "event");
-    check(launch_decode_lds(a, p.min_sum, s), "decode_lds");
+    if (plan_.lds_ok)
+        check(launch_decode_lds(a, p.min_sum, s), "decode (LDS-resident)");
+    else if (plan_.hbm_ok)
+    {
+        a.ws_msg = static_cast<double *>(ws_msg_.reserve(8 * n * nnz));
+        a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
+        a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nnz));
+        // resident frames per CU are bounded through a dummy LDS request so that the frames in flight
+        // (256 CUs x frames/CU x state bytes) stay inside the 256 MiB Infinity Cache
+        const uint64_t per_frame = 8ull * nnz + 8ull * nc + nnz;
+        uint64_t frames_per_cu = std::clamp<uint64_t>((224ull << 20) / (256 * per_frame), 1, 8);
+        if (const char *e = std::getenv("LDPC_AMD_FRAMES_PER_CU"))
+            frames_per_cu = std::clamp<uint64_t>(std::strtoull(e, nullptr, 10), 1, 8);
+        const uint32_t occ_lds = frames_per_cu >= 8 ? 0 : static_cast<uint32_t>((160 * 1024) / (frames_per_cu + 1) + 1024) & ~15u;
+        check(launch_decode_mem(a, p.min_sum, occ_lds, s), "decode (memory-resident)");
+    }
+    else
+        throw std::runtime_error("check-node degree above " + std::to_string(kMaxCnDegree) + " is not supported");
     if (profiling_)
         check(hipEventRecord(static_cast<hipEvent_t>(ev_[1]), s), "event");
     if (out.codeword)
@@ -356,28 +382,135 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
     st.flush(s);
 }
 
+void Engine::run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const uint8_t *codeword, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nc = plan_.nc;
+    const uint64_t nct = static_cast<uint64_t>(plan_.nct);
+    if (((plan_.nnz + 15) / 16) * 16 + 2 * ((nc + 15) / 16) * 16 > 160 * 1024)
+        throw std::runtime_error("code too large for the LDS-resident erasure decoder");
+    OutStage st;
+    BecArgs a{};
+    a.plan = dev_;
+    a.iterations = p.iterations;
+    a.early_term = p.early_term;
+    a.deg1_compat = bec_deg1_compat;
+    a.n_frames = n;
+    a.raw = noise_.generate(raw_next_, n * nct, stream);
+    a.eps = x_;
+    a.codeword = codeword;
+    a.iters = st.route(out.iters, stage_iters_, 4 * n);
+    a.bit_errors = st.route(out.bit_errors, stage_be_, 4 * n);
+    a.hard = st.route(out.hard, stage_hard_, n * nc);
+    a.llr_out = st.route(out.llr_out, stage_llr_out_, 8 * n * nc);
+    a.llr_in_dump = st.route(out.llr_in, stage_llr_in_, 8 * n * nc);
+    if (profiling_)
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), s), "event");
+    check(launch_bec(a, s), "bec");
+    if (profiling_)
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_[1]), s), "event");
+    if (out.codeword)
+    {
+        if (codeword)
+            check(hipMemcpyAsync(out.codeword, codeword, n * nc,
+                                 is_device_ptr(out.codeword) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s),
+                  "codeword out");
+        else if (is_device_ptr(out.codeword))
+            check(hipMemsetAsync(out.codeword, 0, n * nc, s), "codeword out");
+        else
+            std::memset(out.codeword, 0, n * nc);
+    }
+    st.flush(s);
+}
+
+// channel.cpp:44-60 for n consecutive frames (see EncodeArgs in kernels.hpp)
+const uint8_t *Engine::encode_frames(uint64_t n, bool want_codewords, void *stream)
+{
+    if (!code_->has_G() || n == 0)
+        return nullptr;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nc = plan_.nc;
+    const uint64_t kc = static_cast<uint64_t>(code_->kc());
+    if (code_->kc() <= 0 || code_->G.rows > code_->kc())
+        throw std::runtime_error("generator matrix does not match the code (rows > nc - mc)");
+    uint8_t *prev = static_cast<uint8_t *>(cw_run_.reserve(nc));
+    if (!cw_run_valid_)
+    {
+        check(hipMemsetAsync(prev, 0, nc, s), "codeword reset");
+        cw_run_valid_ = true;
+    }
+    check(hipMemcpyAsync(cw_before_.reserve(nc), prev, nc, hipMemcpyDeviceToDevice, s), "codeword snapshot");
+    last_enc_n_ = want_codewords ? n : 0;
+    EncodeArgs e{};
+    e.nc = static_cast<int>(nc);
+    e.kc = static_cast<int>(kc);
+    e.words = static_cast<int>((kc + 63) / 64);
+    e.g_col_ptr = g_col_ptr_;
+    e.g_col_row = g_col_row_;
+    e.g_cols = code_->G.cols;
+    e.info_raw = info_.generate(info_pos_, n * kc, stream);
+    e.prefix = static_cast<uint64_t *>(enc_prefix_.reserve(8 * n * e.words));
+    e.cw_prev = prev;
+    e.codeword = want_codewords ? static_cast<uint8_t *>(cw_frames_.reserve(n * nc)) : nullptr;
+    e.cw_last = static_cast<uint8_t *>(cw_next_.reserve(nc));
+    e.n_frames = n;
+    check(launch_encode(e, s), "encode");
+    check(hipMemcpyAsync(prev, e.cw_last, nc, hipMemcpyDeviceToDevice, s), "codeword carry");
+    info_pos_ += n * kc;
+    return e.codeword;
+}
+
 void Engine::decode_llr(const DecParams &p, uint64_t n, const double *llr_in, const BatchOut &out, void *stream)
 {
     if (n == 0)
         return;
     upload_plan();
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t bytes = 8 * n * static_cast<size_t>(plan_.nc);
-    DecodeArgs a{};
-    a.mode = kModeLlr;
-    if (is_device_ptr(llr_in))
-        a.llr_in = llr_in;
-    else
+    const uint64_t nc = static_cast<uint64_t>(plan_.nc), sub = max_sub_batch();
+    for (uint64_t done = 0; done < n; done += sub)
     {
-        void *d = stage_in_.reserve(bytes);
-        check(hipMemcpyAsync(d, llr_in, bytes, hipMemcpyHostToDevice, s), "copy in");
-        a.llr_in = static_cast<const double *>(d);
+        const uint64_t m = std::min(sub, n - done);
+        const size_t bytes = 8 * m * nc;
+        BatchOut o = out;
+        if (o.iters) o.iters += done;
+        if (o.bit_errors) o.bit_errors += done;
+        if (o.hard) o.hard += done * nc;
+        if (o.llr_out) o.llr_out += done * nc;
+        if (o.llr_in) o.llr_in += done * nc;
+        if (o.codeword) o.codeword += done * nc;
+        DecodeArgs a{};
+        a.mode = kModeLlr;
+        const double *src = llr_in + done * nc;
+        if (is_device_ptr(src))
+            a.llr_in = src;
+        else
+        {
+            void *d = stage_in_.reserve(bytes);
+            check(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s), "copy in");
+            a.llr_in = static_cast<const double *>(d);
+        }
+        run_decode(a, p, o, m, stream);
     }
-    run_decode(a, p, out, n, stream);
+}
+
+void Engine::stream_rewind_encoder(uint64_t frames_back, void *stream)
+{
+    if (!code_->has_G() || frames_back == 0)
+        return;
+    if (frames_back > last_enc_n_)
+        throw std::runtime_error("stream_rewind_encoder: more frames than the last batch held");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nc = plan_.nc;
+    const uint8_t *src = frames_back == last_enc_n_
+                             ? static_cast<const uint8_t *>(cw_before_.get())
+                             : static_cast<const uint8_t *>(cw_frames_.get()) + (last_enc_n_ - frames_back - 1) * nc;
+    check(hipMemcpyAsync(cw_run_.get(), src, nc, hipMemcpyDeviceToDevice, s), "codeword rewind");
+    info_pos_ -= frames_back * static_cast<uint64_t>(code_->kc());
+    last_enc_n_ = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-void Engine::stream_begin(int channel, uint64_t seed, double x)
+void Engine::stream_begin(int channel, uint64_t seed, double x, bool fresh)
 {
     if (channel != kAwgn && channel != kBsc && channel != kBec)
         throw std::runtime_error("No channel selected.");
@@ -387,6 +520,12 @@ void Engine::stream_begin(int channel, uint64_t seed, double x)
     pair_next_ = 0;
     raw_next_ = 0;
     noise_.reset(seed);
+    if (fresh || info_.seed() != (seed << 1))
+    {
+        info_.reset(seed << 1); // channel.cpp:11
+        info_pos_ = 0;
+        cw_run_valid_ = false;
+    }
     if (channel == kAwgn)
     {
         sigma2_ = std::pow(10, -x / 10); // channel.cpp:39
@@ -453,6 +592,7 @@ void Engine::stream_skip(uint64_t n_frames, void *stream)
     while (n_frames)
     {
         const uint64_t n = std::min<uint64_t>(n_frames, 1u << 17);
+        encode_frames(n, false, stream);
         if (chan_ == kAwgn)
         {
             DecodeArgs a{};
@@ -472,13 +612,12 @@ void Engine::stream_decode(const DecParams &p, uint64_t n_frames, const BatchOut
     if (n_frames == 0)
         return;
     upload_plan();
-    if (code_->has_G())
-        throw std::runtime_error("encoding with a generator matrix is not built yet");
     const uint64_t nct = static_cast<uint64_t>(plan_.nct), nc = static_cast<uint64_t>(plan_.nc);
+    const uint64_t sub = max_sub_batch();
     uint64_t done = 0;
     while (done < n_frames)
     {
-        const uint64_t n = std::min<uint64_t>(n_frames - done, 1u << 17);
+        const uint64_t n = std::min<uint64_t>(n_frames - done, sub);
         BatchOut o = out;
         if (o.iters) o.iters += done;
         if (o.bit_errors) o.bit_errors += done;
@@ -486,11 +625,13 @@ void Engine::stream_decode(const DecParams &p, uint64_t n_frames, const BatchOut
         if (o.llr_out) o.llr_out += done * nc;
         if (o.llr_in) o.llr_in += done * nc;
         if (o.codeword) o.codeword += done * nc;
+        PhaseTrace tr;
+        const uint8_t *cw = encode_frames(n, true, stream);
         DecodeArgs a{};
+        a.codeword = cw;
         if (chan_ == kAwgn)
         {
             a.mode = kModeAwgn;
-            PhaseTrace tr;
             awgn_prepare(n, a, stream);
             tr.mark("awgn_prepare");
             run_decode(a, p, o, n, stream);
@@ -502,11 +643,14 @@ void Engine::stream_decode(const DecParams &p, uint64_t n_frames, const BatchOut
             a.raw = noise_.generate(raw_next_, n * nct, stream);
             a.eps = x_, a.delta = delta_;
             a.shorten_llr = delta_; // channel.cpp:152
-            raw_next_ += n * nct;
             run_decode(a, p, o, n, stream);
+            raw_next_ += n * nct;
         }
         else
-            throw std::runtime_error("BEC decoder is not built yet");
+        {
+            run_bec(p, o, n, cw, stream);
+            raw_next_ += n * nct;
+        }
         frame_pos_ += n;
         done += n;
     }

@@ -99,13 +99,20 @@ class Engine
 
     // ---- fused channel + decode on the reference's noise stream ----
     // set_channel_param semantics (channel.cpp:37-42): the stream restarts at frame 0.
-    void stream_begin(int channel, uint64_t seed, double x);
+    // `fresh` also resets the encoder (info-word stream position and the accumulated codeword), i.e. a
+    // newly constructed channel object; the reference keeps both across channel points of one run.
+    void stream_begin(int channel, uint64_t seed, double x, bool fresh = true);
     void stream_skip(uint64_t n_frames, void *stream);
     void stream_decode(const DecParams &p, uint64_t n_frames, const BatchOut &out, void *stream);
+    // Un-consume the last `frames_back` frames of the most recent stream_decode batch from the ENCODER state
+    // (info-word stream position and accumulated codeword), so that the next channel point continues where a
+    // frame-by-frame run that stopped inside the batch would (the noise stream restarts per point anyway).
+    void stream_rewind_encoder(uint64_t frames_back, void *stream);
     uint64_t stream_frame() const { return frame_pos_; }
     uint64_t stream_raw_draws() const;
 
     void synchronize(void *stream);
+    uint64_t max_sub_batch() const; // frames one launch takes; larger requests are split
 
     // kernel timing with HIP events on the launch stream (bench.py's roofline figure)
     void set_profiling(bool on);
@@ -115,7 +122,11 @@ class Engine
   private:
     void upload_plan();
     void run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, uint64_t n, void *stream);
+    void run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const uint8_t *codeword, void *stream);
     void awgn_prepare(uint64_t n_frames, DecodeArgs &a, void *stream);
+    // advance the encoder by n frames; returns the per-frame codewords [n][nc] (nullptr when no G is
+    // loaded, or when want_codewords is false)
+    const uint8_t *encode_frames(uint64_t n, bool want_codewords, void *stream);
 
     std::unique_ptr<LdpcCode> code_;
     Plan plan_;
@@ -129,10 +140,15 @@ class Engine
     uint64_t frame_pos_ = 0;
     uint64_t pair_next_ = 0; // accepted polar pairs located so far
     uint64_t raw_next_ = 0;  // raw draws consumed so far (AWGN: where the next trial starts)
-    MtStream noise_;
+    MtStream noise_, info_;
+    uint64_t info_pos_ = 0;     // info-word draws consumed (kc per frame)
+    bool cw_run_valid_ = false; // cw_run_ holds the accumulated codeword
+    DeviceBuffer cw_run_, cw_next_, cw_frames_, cw_before_, enc_prefix_;
+    uint64_t last_enc_n_ = 0;   // frames of the last encode_frames call that produced cw_frames_
+    const uint32_t *g_col_ptr_ = nullptr, *g_col_row_ = nullptr;
     DeviceBuffer pairs_, carry_, scan_counts_, scan_offsets_, scan_result_;
     DeviceBuffer stage_in_, stage_iters_, stage_be_, stage_hard_, stage_llr_out_, stage_llr_in_, stage_cw_;
-    DeviceBuffer hbm_msg_, hbm_llr_, hbm_hard_;
+    DeviceBuffer ws_msg_, ws_llr_, ws_hb_;
     bool profiling_ = false;
     void *ev_[4] = {nullptr, nullptr, nullptr, nullptr};
 };

@@ -1,8 +1,11 @@
 // kernels.hip — hand-written HIP kernels for gfx950 (MI355X, wave64).
 //
 // Hot path of heat1q/libldpc rebuilt for CDNA4: flooding BP (sum-product / min-sum) with the
-// channel + LLR initialisation fused into the same launch.  One workgroup decodes one frame with
-// all of its messages resident in LDS; thousands of frames per launch.
+// channel + LLR initialisation fused into the same launch.  One workgroup decodes one frame;
+// thousands of frames per launch.  Two residencies of the per-frame state share one kernel body:
+//   LDS-resident     (n=1024 test code: 40 KB per frame, 4 frames per CU)
+//   memory-resident  (codes that do not fit LDS, e.g. n=8192: the frames in flight are sized to stay
+//                     inside the 256 MiB Infinity Cache)
 //
 // Reference semantics restated here (file:line in heat1q/libldpc):
 //   decode loop            src/decoding/decoder.cpp:11-78
@@ -11,6 +14,7 @@
 //   AWGN channel + LLRs    src/sim/channel.cpp:62-93   (libstdc++ normal_distribution, polar method)
 //   BSC channel + LLRs     src/sim/channel.cpp:129-162
 //   BEC channel + decoder  src/sim/channel.cpp:199-229, src/decoding/decoder.cpp:91-192
+//   encoder                src/sim/channel.cpp:44-60, src/core/sparse.h:163-172
 //   bit-error count        src/sim/ldpcsim.cpp:184-188
 #include <hip/hip_runtime.h>
 
@@ -24,10 +28,11 @@ namespace
 {
 
 constexpr int kThreads = kDecodeWaves * kWaveSize;
+constexpr uint8_t kErasure = 'E'; // functions.h:105
 
 // ---------------------------------------------------------------------------------------------
 // check-node update of one node held by one lane: forward/backward recursion, decoder.cpp:31-44.
-// v[j] = v2c of the node's j-th edge (row file order); returns c2v in place.  The reference also
+// m[j*stride] = v2c of the node's j-th edge (row file order); replaced by c2v.  The reference also
 // evaluates F[cw-1] and B[0], which nothing reads; they are skipped.
 // ---------------------------------------------------------------------------------------------
 template <int D, bool MINSUM>
@@ -52,7 +57,7 @@ __device__ __forceinline__ void cn_update(double *m, int stride)
         m[j * stride] = boxplus<MINSUM>(F[j - 1], B[j + 1]);
 }
 
-template <bool MINSUM>
+template <bool MINSUM, int MAXD>
 __device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane)
 {
     if (lane >= b.count)
@@ -68,7 +73,23 @@ __device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane)
     case 6: cn_update<6, MINSUM>(m, s); break;
     case 7: cn_update<7, MINSUM>(m, s); break;
     case 8: cn_update<8, MINSUM>(m, s); break;
-    default: break;
+    default:
+        if constexpr (MAXD > 8)
+        {
+            switch (b.degree)
+            {
+            case 9: cn_update<9, MINSUM>(m, s); break;
+            case 10: cn_update<10, MINSUM>(m, s); break;
+            case 11: cn_update<11, MINSUM>(m, s); break;
+            case 12: cn_update<12, MINSUM>(m, s); break;
+            case 13: cn_update<13, MINSUM>(m, s); break;
+            case 14: cn_update<14, MINSUM>(m, s); break;
+            case 15: cn_update<15, MINSUM>(m, s); break;
+            case 16: cn_update<16, MINSUM>(m, s); break;
+            default: break;
+            }
+        }
+        break;
     }
 }
 
@@ -81,26 +102,38 @@ __device__ __forceinline__ int wave_sum(int v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-resident decoder: one workgroup (4 waves) per frame.
-//   LDS: msg[nnz] f64 (v2c and c2v share the slot: each edge is rewritten by its own CN lane,
-//        then by its own VN lane), llr[nc] f64 (VN rank order), hb[nnz] u8 (hard decision of the
-//        edge's VN, read back by the CN lanes for the syndrome).
+// BP / min-sum decoder, one workgroup (4 waves) per frame.
+//   per-frame state: msg[nnz] f64 (v2c and c2v share the slot: each edge is rewritten by its own CN
+//   lane, then by its own VN lane), llr[nc] f64 (VN rank order), hb[nnz] u8 (hard decision of the
+//   edge's VN, read back by the CN lanes for the syndrome).
 // ---------------------------------------------------------------------------------------------
-template <bool MINSUM, bool WANT_LLR>
-__global__ __launch_bounds__(kThreads) void decode_lds_kernel(const DecodeArgs a)
+template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT>
+__global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 {
     extern __shared__ double lds[];
+    __shared__ int misc[4];
     const DevPlan &P = a.plan;
     const int nnz = P.nnz, nc = P.nc, nct = P.nct;
-    double *msg = lds;
-    double *llr = lds + nnz;
-    uint8_t *hb = reinterpret_cast<uint8_t *>(llr + nc);
-    int *misc = reinterpret_cast<int *>(hb + ((nnz + 15) / 16) * 16);
+    const uint64_t frame = blockIdx.x;
+    double *msg, *llr;
+    uint8_t *hb;
+    if constexpr (LDS_RESIDENT)
+    {
+        msg = lds;
+        llr = lds + nnz;
+        hb = reinterpret_cast<uint8_t *>(llr + nc);
+    }
+    else
+    {
+        msg = a.ws_msg + frame * nnz;
+        llr = a.ws_llr + frame * nc;
+        hb = a.ws_hb + frame * nnz;
+    }
+    constexpr int MAXD = LDS_RESIDENT ? kMaxLdsCnDegree : kMaxCnDegree;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const uint64_t frame = blockIdx.x;
     const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
 
     if (tid == 0)
@@ -182,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void decode_lds_kernel(const DecodeArgs a
         if (lane < b.count)
         {
             double L = llr[b.first + lane];
-            const uint16_t *idx = P.vn_slot + b.idx_off + lane;
+            const uint32_t *idx = P.vn_slot + b.idx_off + lane;
             for (int p = 0; p < b.degree; ++p)
                 msg[idx[p * b.count]] = L;
         }
@@ -199,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void decode_lds_kernel(const DecodeArgs a
             uint16_t bi = my_cn[w];
             if (bi == 0xFFFF)
                 break;
-            cn_block<MINSUM>(msg, P.cn_blocks[bi], lane);
+            cn_block<MINSUM, MAXD>(msg, P.cn_blocks[bi], lane);
         }
         __syncthreads();
 
@@ -213,14 +246,14 @@ __global__ __launch_bounds__(kThreads) void decode_lds_kernel(const DecodeArgs a
             if (lane < b.count)
             {
                 const int r = b.first + lane;
-                const uint16_t *idx = P.vn_slot + b.idx_off + lane;
+                const uint32_t *idx = P.vn_slot + b.idx_off + lane;
                 double out = llr[r];
                 for (int p = 0; p < b.degree; ++p) // sequential sum in column file order
                     out += msg[idx[p * b.count]];
                 const uint8_t bit = out <= 0;
                 for (int p = 0; p < b.degree; ++p)
                 {
-                    const int s = idx[p * b.count];
+                    const uint32_t s = idx[p * b.count];
                     msg[s] = out - msg[s];
                     hb[s] = bit;
                 }
@@ -261,8 +294,8 @@ __global__ __launch_bounds__(kThreads) void decode_lds_kernel(const DecodeArgs a
     auto hard_of_rank = [&](int r) -> int {
         if (!ran)
             return 0; // mCO is still zero-initialised when no iteration ran
-        uint16_t s0 = P.rank_slot0[r];
-        return s0 != 0xFFFF ? hb[s0] : static_cast<int>(llr[r] <= 0);
+        uint32_t s0 = P.rank_slot0[r];
+        return s0 != kNoSlot ? hb[s0] : static_cast<int>(llr[r] <= 0);
     };
     if (a.hard)
     {
@@ -277,7 +310,7 @@ __global__ __launch_bounds__(kThreads) void decode_lds_kernel(const DecodeArgs a
                 out_llr[P.rank_col[r]] = 0.0;
         else // isolated variable nodes never pass through a VN block with edges
             for (int r = tid; r < nc; r += kThreads)
-                if (P.rank_slot0[r] == 0xFFFF)
+                if (P.rank_slot0[r] == kNoSlot)
                     out_llr[P.rank_col[r]] = llr[r];
     }
     if (a.bit_errors)
@@ -298,24 +331,365 @@ __global__ __launch_bounds__(kThreads) void decode_lds_kernel(const DecodeArgs a
     }
 }
 
-} // namespace
+// ---------------------------------------------------------------------------------------------
+// BEC: erasure decoder over the alphabet {0, 1, 'E'} (decoder.cpp:91-192), channel fused
+// (channel.cpp:199-229).  All state is bytes in LDS: msg[nnz], sym[nc] (decoder input), lout[nc].
+//
+// The reference runs the forward/backward recursion with
+//   cn_update(l, r) = 'E' if either is 'E' else l xor r                      (decoder.h:152-155)
+//   vn_update(l, r, x) = x if either equals x else 'E'                       (decoder.h:145-148)
+// Both recursions have closed forms over the node's other edges, used here (integer alphabet: the
+// results are the same values, not approximations):
+//   check node, edge j: 'E' if any other input is 'E', else the xor of the other inputs;
+//   erased VN of degree >= 3, edge j: x if any other input equals x, else 'E';
+//   erased VN of degree 2: the other input unchanged; degree 1: see deg1_compat.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void bec_kernel(const BecArgs a)
+{
+    extern __shared__ double lds[];
+    __shared__ int misc[4];
+    const DevPlan &P = a.plan;
+    const int nnz = P.nnz, nc = P.nc, nct = P.nct;
+    uint8_t *msg = reinterpret_cast<uint8_t *>(lds);
+    uint8_t *sym = msg + ((nnz + 15) / 16) * 16;
+    uint8_t *lout = sym + ((nc + 15) / 16) * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t frame = blockIdx.x;
+    const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
+    auto cw_of_rank = [&](int r) -> uint8_t { return cw ? cw[P.rank_col[r]] : 0; };
 
-int launch_decode_lds(const DecodeArgs &a, bool min_sum, void *stream)
+    if (tid == 0)
+        misc[0] = 0;
+    // ---- channel: channel.cpp:199-229 ----
+    if (a.raw)
+    {
+        for (int r = tid; r < nc; r += kThreads)
+        {
+            uint8_t k = P.rank_kind[r];
+            if (k == 1)
+                sym[r] = kErasure;
+            else if (k == 2)
+            {
+                // channel.cpp:222 indexes the transmitted-symbol vector by the COLUMN index
+                uint32_t col = P.rank_col[r];
+                sym[r] = (col < static_cast<uint32_t>(nct) && cw) ? cw[P.bit_pos[col]] : 0;
+            }
+        }
+        const uint64_t *raw = a.raw + frame * static_cast<uint64_t>(nct);
+        for (int i = tid; i < nct; i += kThreads)
+        {
+            bool erased = canonical(raw[i]) < a.eps;
+            uint8_t xb = cw ? cw[P.bit_pos[i]] : 0;
+            sym[P.tx_rank[i]] = erased ? kErasure : xb;
+        }
+    }
+    else
+    {
+        const uint8_t *in = a.symbols + frame * nc;
+        for (int r = tid; r < nc; r += kThreads)
+            sym[r] = in[P.rank_col[r]];
+    }
+    __syncthreads();
+    if (a.llr_in_dump)
+    {
+        double *o = a.llr_in_dump + frame * nc;
+        for (int r = tid; r < nc; r += kThreads)
+            o[P.rank_col[r]] = static_cast<double>(sym[r]);
+    }
+    for (int r = tid; r < nc; r += kThreads)
+        lout[r] = 0; // mLLROut starts zeroed
+
+    const uint16_t *my_vn = P.vn_work + wave * P.vn_work_stride;
+    const uint16_t *my_cn = P.cn_work + wave * P.cn_work_stride;
+    // v2c init: decoder.cpp:96-99
+    for (int w = 0; w < P.vn_work_stride; ++w)
+    {
+        uint16_t bi = my_vn[w];
+        if (bi == 0xFFFF)
+            break;
+        const VnBlock b = P.vn_blocks[bi];
+        if (lane < b.count)
+        {
+            uint8_t L = sym[b.first + lane];
+            const uint32_t *idx = P.vn_slot + b.idx_off + lane;
+            for (int p = 0; p < b.degree; ++p)
+                msg[idx[p * b.count]] = L;
+        }
+    }
+    __syncthreads();
+
+    uint32_t I = 0;
+    while (I < a.iterations)
+    {
+        // ---- CN update: decoder.cpp:105-123 ----
+        for (int w = 0; w < P.cn_work_stride; ++w)
+        {
+            uint16_t bi = my_cn[w];
+            if (bi == 0xFFFF)
+                break;
+            const CnBlock b = P.cn_blocks[bi];
+            if (lane < b.count)
+            {
+                uint8_t *m = msg + b.off + lane;
+                int n_e = 0, x = 0;
+                for (int j = 0; j < b.degree; ++j)
+                {
+                    uint8_t v = m[j * b.count];
+                    if (v == kErasure)
+                        ++n_e;
+                    else
+                        x ^= (v != 0);
+                }
+                for (int j = 0; j < b.degree; ++j)
+                {
+                    uint8_t v = m[j * b.count];
+                    uint8_t o;
+                    if (v == kErasure)
+                        o = (n_e == 1) ? static_cast<uint8_t>(x) : kErasure;
+                    else
+                        o = (n_e == 0) ? static_cast<uint8_t>(x ^ (v != 0)) : kErasure;
+                    m[j * b.count] = o;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- VN update: decoder.cpp:126-167 ----
+        int any_e = 0;
+        for (int w = 0; w < P.vn_work_stride; ++w)
+        {
+            uint16_t bi = my_vn[w];
+            if (bi == 0xFFFF)
+                break;
+            const VnBlock b = P.vn_blocks[bi];
+            if (lane < b.count)
+            {
+                const int r = b.first + lane;
+                const uint32_t *idx = P.vn_slot + b.idx_off + lane;
+                const uint8_t x = cw_of_rank(r);
+                const int vw = b.degree;
+                if (sym[r] != kErasure)
+                {
+                    for (int p = 0; p < vw; ++p)
+                        msg[idx[p * b.count]] = x;
+                    lout[r] = x;
+                }
+                else if (vw == 0)
+                {
+                    // no edges: the reference would index an empty neighbour list; keep the erasure
+                    lout[r] = kErasure;
+                }
+                else if (vw == 1)
+                {
+                    uint8_t c0 = msg[idx[0]];
+                    msg[idx[0]] = a.deg1_compat ? 0 : kErasure;
+                    lout[r] = c0;
+                }
+                else if (vw == 2)
+                {
+                    uint8_t c0 = msg[idx[0]], c1 = msg[idx[b.count]];
+                    msg[idx[0]] = c1;
+                    msg[idx[b.count]] = c0;
+                    lout[r] = (c0 == x || c1 == x) ? x : kErasure;
+                }
+                else
+                {
+                    int hits = 0;
+                    for (int p = 0; p < vw; ++p)
+                        hits += msg[idx[p * b.count]] == x;
+                    for (int p = 0; p < vw; ++p)
+                    {
+                        const uint32_t s = idx[p * b.count];
+                        int own = msg[s] == x;
+                        msg[s] = (hits - own) > 0 ? x : kErasure;
+                    }
+                    lout[r] = hits > 0 ? x : kErasure;
+                }
+                any_e |= lout[r] == kErasure;
+            }
+        }
+        // early termination when no erasure is left (decoder.cpp:169-186); also the barrier of the pass
+        if (a.early_term)
+        {
+            if (!__syncthreads_or(any_e))
+                break;
+        }
+        else
+            __syncthreads();
+        ++I;
+    }
+    __syncthreads();
+
+    if (tid == 0 && a.iters)
+        a.iters[frame] = I;
+    const bool ran = a.iterations > 0;
+    // mCO: decoder.cpp:137,165 — the true bit, or 1 when the VN is still erased (-gf2 is always 1)
+    auto hard_of_rank = [&](int r) -> int {
+        if (!ran)
+            return 0;
+        return lout[r] == kErasure ? 1 : cw_of_rank(r);
+    };
+    if (a.hard)
+    {
+        uint8_t *h = a.hard + frame * nc;
+        for (int r = tid; r < nc; r += kThreads)
+            h[P.rank_col[r]] = static_cast<uint8_t>(hard_of_rank(r));
+    }
+    if (a.llr_out)
+    {
+        double *o = a.llr_out + frame * nc;
+        for (int r = tid; r < nc; r += kThreads)
+            o[P.rank_col[r]] = static_cast<double>(lout[r]);
+    }
+    if (a.bit_errors)
+    {
+        int err = 0;
+        for (int i = tid; i < nct; i += kThreads)
+        {
+            int r = P.tx_rank[i];
+            err += hard_of_rank(r) != static_cast<int>(cw_of_rank(r));
+        }
+        err = wave_sum(err);
+        if (lane == 0 && err)
+            atomicAdd(&misc[0], err);
+        __syncthreads();
+        if (tid == 0)
+            a.bit_errors[frame] = static_cast<uint32_t>(misc[0]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// encoder (see EncodeArgs)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void encode_info_kernel(const EncodeArgs a)
+{
+    // one thread per (frame, word): 64 bernoulli(0.5) draws -> one packed word
+    const uint64_t gid = static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (gid >= a.n_frames * static_cast<uint64_t>(a.words))
+        return;
+    const uint64_t f = gid / a.words;
+    const int w = static_cast<int>(gid % a.words);
+    const uint64_t *raw = a.info_raw + f * static_cast<uint64_t>(a.kc) + 64 * w;
+    const int nb = min(64, a.kc - 64 * w);
+    uint64_t bits = 0;
+    for (int i = 0; i < nb; ++i)
+        bits |= static_cast<uint64_t>(canonical(raw[i]) < 0.5) << i;
+    a.prefix[gid] = bits;
+}
+
+// running XOR over frames, one workgroup per packed word column
+__global__ __launch_bounds__(1024) void encode_prefix_kernel(const EncodeArgs a)
+{
+    __shared__ uint64_t part[1024];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const uint64_t per = (a.n_frames + 1023) / 1024;
+    const uint64_t lo = min(tid * per, a.n_frames), hi = min(lo + per, a.n_frames);
+    uint64_t s = 0;
+    for (uint64_t f = lo; f < hi; ++f)
+        s ^= a.prefix[f * a.words + w];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1)
+    {
+        uint64_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] ^= v;
+        __syncthreads();
+    }
+    uint64_t run = tid ? part[tid - 1] : 0;
+    for (uint64_t f = lo; f < hi; ++f)
+    {
+        run ^= a.prefix[f * a.words + w];
+        a.prefix[f * a.words + w] = run;
+    }
+}
+
+// codeword[f][j] = cw_prev[j] ^ parity(prefix_f restricted to the rows of column j of G)
+__global__ __launch_bounds__(256) void encode_cw_kernel(const EncodeArgs a, uint64_t first_frame)
+{
+    extern __shared__ uint64_t pw[];
+    const uint64_t f = first_frame + blockIdx.x;
+    for (int w = threadIdx.x; w < a.words; w += 256)
+        pw[w] = a.prefix[f * a.words + w];
+    __syncthreads();
+    const bool last = f + 1 == a.n_frames;
+    uint8_t *out = a.codeword ? a.codeword + f * a.nc : nullptr;
+    for (int j = threadIdx.x; j < a.nc; j += 256)
+    {
+        uint8_t b = a.cw_prev[j];
+        if (j < a.g_cols)
+            for (uint32_t p = a.g_col_ptr[j]; p < a.g_col_ptr[j + 1]; ++p)
+            {
+                uint32_t r = a.g_col_row[p];
+                b ^= static_cast<uint8_t>(pw[r >> 6] >> (r & 63) & 1);
+            }
+        if (out)
+            out[j] = b;
+        if (last)
+            a.cw_last[j] = b;
+    }
+}
+
+template <bool LDS_RESIDENT>
+int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *stream)
 {
     if (a.n_frames == 0)
         return hipSuccess;
     const bool want_llr = a.llr_out != nullptr;
     void (*k)(const DecodeArgs) = nullptr;
     if (min_sum)
-        k = want_llr ? decode_lds_kernel<true, true> : decode_lds_kernel<true, false>;
+        k = want_llr ? decode_kernel<true, true, LDS_RESIDENT> : decode_kernel<true, false, LDS_RESIDENT>;
     else
-        k = want_llr ? decode_lds_kernel<false, true> : decode_lds_kernel<false, false>;
+        k = want_llr ? decode_kernel<false, true, LDS_RESIDENT> : decode_kernel<false, false, LDS_RESIDENT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(a.plan.lds_bytes));
+                                       static_cast<int>(lds_bytes));
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(a.n_frames)), dim3(kThreads), a.plan.lds_bytes,
+    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(a.n_frames)), dim3(kThreads), lds_bytes,
                        static_cast<hipStream_t>(stream), a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+int launch_decode_lds(const DecodeArgs &a, bool min_sum, void *stream)
+{
+    return launch_decode<true>(a, min_sum, a.plan.lds_bytes, stream);
+}
+
+int launch_decode_mem(const DecodeArgs &a, bool min_sum, uint32_t occupancy_lds, void *stream)
+{
+    if (!a.ws_msg || !a.ws_llr || !a.ws_hb)
+        return hipErrorInvalidValue;
+    return launch_decode<false>(a, min_sum, occupancy_lds, stream);
+}
+
+int launch_bec(const BecArgs &a, void *stream)
+{
+    if (a.n_frames == 0)
+        return hipSuccess;
+    const uint32_t lds = ((a.plan.nnz + 15) / 16) * 16 + 2 * (((a.plan.nc + 15) / 16) * 16);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bec_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(bec_kernel, dim3(static_cast<unsigned>(a.n_frames)), dim3(kThreads), lds,
+                       static_cast<hipStream_t>(stream), a);
+    return hipGetLastError();
+}
+
+int launch_encode(const EncodeArgs &a, void *stream)
+{
+    if (a.n_frames == 0)
+        return hipSuccess;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t items = a.n_frames * static_cast<uint64_t>(a.words);
+    hipLaunchKernelGGL(encode_info_kernel, dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(encode_prefix_kernel, dim3(a.words), dim3(1024), 0, s, a);
+    const size_t lds = sizeof(uint64_t) * a.words;
+    if (a.codeword)
+        hipLaunchKernelGGL(encode_cw_kernel, dim3(static_cast<unsigned>(a.n_frames)), dim3(256), lds, s, a, uint64_t(0));
+    else // only the running codeword after the batch is wanted
+        hipLaunchKernelGGL(encode_cw_kernel, dim3(1), dim3(256), lds, s, a, a.n_frames - 1);
     return hipGetLastError();
 }
 

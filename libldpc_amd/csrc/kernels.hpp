@@ -16,17 +16,15 @@ struct DevPlan
     int cn_work_stride, vn_work_stride;
     const CnBlock *cn_blocks;
     const VnBlock *vn_blocks;
-    const uint16_t *vn_slot;
+    const uint32_t *vn_slot;
     const uint16_t *cn_work;
     const uint16_t *vn_work;
-    const uint16_t *col_rank;
-    const uint16_t *rank_col;
-    const uint16_t *tx_rank;
+    const uint32_t *col_rank;
+    const uint32_t *rank_col;
+    const uint32_t *tx_rank;
     const uint8_t *rank_kind;
-    const uint16_t *rank_slot0;
+    const uint32_t *rank_slot0;
     const int *bit_pos; // [nct] transmitted index -> column
-    // HBM-resident decoder tables
-    const uint32_t *row_ptr, *row_edge_col, *col_ptr, *col_edge;
     uint32_t lds_bytes;
 };
 
@@ -64,6 +62,10 @@ struct DecodeArgs
     uint8_t *hard;        // [n_frames][nc]
     double *llr_out;      // [n_frames][nc]
     double *llr_in_dump;  // [n_frames][nc]
+    // memory-resident decoder only: per-frame state in device memory instead of LDS
+    double *ws_msg;  // [n_frames][nnz]
+    double *ws_llr;  // [n_frames][nc]
+    uint8_t *ws_hb;  // [n_frames][nnz]
 };
 
 // BEC (u8 erasure alphabet, decoder.cpp:91-192 + channel.cpp:199-229)
@@ -81,16 +83,16 @@ struct BecArgs
     uint32_t *iters;
     uint32_t *bit_errors;
     uint8_t *hard;
-    uint8_t *llr_out;
-    uint8_t *llr_in_dump;
+    double *llr_out;     // symbol values 0, 1, 'E' widened to double
+    double *llr_in_dump;
 };
 
 // All launchers enqueue on `stream` (hipStream_t passed as void*) and return a hipError_t as int.
 int launch_decode_lds(const DecodeArgs &a, bool min_sum, void *stream);
-int launch_decode_hbm(const DecodeArgs &a, bool min_sum, double *msg_ws, double *llr_ws, uint8_t *hard_ws,
-                      void *stream);
+// memory-resident variant for codes whose messages do not fit LDS (a.ws_* must be set); occupancy_lds
+// bytes of dynamic LDS are requested only to bound the number of resident frames per CU
+int launch_decode_mem(const DecodeArgs &a, bool min_sum, uint32_t occupancy_lds, void *stream);
 int launch_bec(const BecArgs &a, void *stream);
-size_t hbm_workspace_bytes(const DevPlan &p, uint64_t n_frames, int which);
 
 // ---- mt19937_64 on the device ----
 constexpr int kMtN = 312;
@@ -119,18 +121,23 @@ constexpr uint32_t kScanBlock = 2048;
 int launch_polar_scan(const uint64_t *raw, uint64_t n_trials, uint64_t want_pairs, uint32_t *block_counts,
                       uint64_t *block_offsets, uint64_t *pairs_out, ScanResult *result, void *stream);
 
-// GF(2) encode u*G accumulated into the running codeword (channel.cpp:44-60):
-//   info bits come from raw draws info_raw[frame*kc + i] (bernoulli(0.5): u < 0.5)
+// GF(2) encoding on the reference's info-word stream (channel.cpp:44-60, sparse.h:163-172).
+// The reference draws kc bernoulli(0.5) bits per frame from mt19937_64(seed << 1) and ACCUMULATES u*G
+// into the codeword it never clears, so the codeword of frame f is cw_prev ^ (u_0 ^ ... ^ u_f) G:
+//   encode_info_kernel   info bit i of frame f = canonical(info_raw[f*kc + i]) < 0.5, packed 64 per word
+//   encode_prefix_kernel running XOR of the packed info words over the frames of the batch
+//   encode_cw_kernel     codeword[f][j] = cw_prev[j] ^ parity of (prefix_f AND column j of G)
 struct EncodeArgs
 {
-    int nc, kc;
-    const uint32_t *g_col_ptr; // [nc+1] CSC of G
+    int nc, kc, words;         // words = ceil(kc/64)
+    const uint32_t *g_col_ptr; // [g_cols+1] CSC of G (row indices per column)
     const uint32_t *g_col_row; // [g_nnz]
+    int g_cols;
     const uint64_t *info_raw;  // [n_frames][kc]
-    const uint8_t *cw_prev;    // [nc] running codeword before this batch
-    uint8_t *codeword;         // [n_frames][nc] out: codeword of each frame
-    uint8_t *cw_last;          // [nc] out: codeword after the batch
-    uint8_t *info_bits;        // [n_frames][kc] scratch
+    uint64_t *prefix;          // [n_frames][words] scratch / result
+    const uint8_t *cw_prev;    // [nc]
+    uint8_t *codeword;         // [n_frames][nc], may be nullptr (skip: only cw_last is wanted)
+    uint8_t *cw_last;          // [nc] codeword after the batch
     uint64_t n_frames;
 };
 int launch_encode(const EncodeArgs &a, void *stream);

@@ -1,0 +1,158 @@
+// ldpcsim — command line front end, drop-in for the reference's `ldpcsim` (src/sim_cpu.cpp:5-85):
+//
+//   ldpcsim codefile output-file MIN MAX STEP [-G file] [-i 50] [-s 0] [-t 1] [--channel AWGN|BSC|BEC]
+//           [--decoding BP|BP_MS] [--max-frames N] [--frame-error-count 50] [--no-early-term]
+//
+// Same positional arguments, flags, defaults, console table and result file; the frames are decoded on
+// the GPU in batches of the reference's single noise stream (seed as given; -t is accepted and ignored:
+// the batch replaces the OpenMP threads).  Extra flag: --device N (GPU index), --bec-compat (reproduce the
+// reference's out-of-bounds read for erased degree-1 variable nodes).
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ldpc_amd.h"
+
+namespace
+{
+const char *kUsage =
+    "Usage: ldpc [options] codefile output-file snr-range \n\n"
+    "Positional arguments:\n"
+    "codefile            \tLDPC parity-check matrix file containing all non-zero entries.\n"
+    "output-file         \tResults output file.\n"
+    "snr-range           \t{MIN} {MAX} {STEP}\n\n"
+    "Optional arguments:\n"
+    "-h --help           \tshows help message and exits\n"
+    "-G --gen-matrix     \tGenerator matrix file.\n"
+    "-i --num-iterations \tNumber of iterations for decoding. (Default: 50)\n"
+    "-s --seed           \tRNG seed. (Default: 0)\n"
+    "-t --num-threads    \tNumber of frames to be decoded in parallel. (Default: 1; ignored: GPU batches)\n"
+    "--channel           \tSpecifies channel: \"AWGN\", \"BSC\", \"BEC\" (Default: AWGN)\n"
+    "--decoding          \tSpecifies decoding algorithm: \"BP\", \"BP_MS\" (Default: BP)\n"
+    "--max-frames        \tLimit number of decoded frames.\n"
+    "--frame-error-count \tMaximum frame errors for given simulation point.\n"
+    "--no-early-term     \tDisable early termination for decoding.\n"
+    "--device            \tGPU index. (Default: 0)\n"
+    "--bec-compat        \tBEC: erased degree-1 variable nodes emit 0 as the reference build does.\n";
+
+[[noreturn]] void fail(const std::string &msg)
+{
+    std::cout << msg << std::endl << kUsage;
+    std::exit(EXIT_FAILURE);
+}
+} // namespace
+
+int main(int argc, char *argv[])
+{
+    std::vector<std::string> pos;
+    std::string gen, channel = "AWGN", decoding = "BP";
+    unsigned iterations = 50, threads = 1;
+    unsigned long seed = 0, max_frames = static_cast<unsigned long>(10e9), fec = 50;
+    bool no_early = false, bec_compat = false;
+    int device = 0;
+    try
+    {
+        for (int i = 1; i < argc; ++i)
+        {
+            std::string a = argv[i];
+            auto value = [&]() -> std::string {
+                if (i + 1 >= argc)
+                    throw std::runtime_error("missing value for " + a);
+                return argv[++i];
+            };
+            if (a == "-h" || a == "--help")
+            {
+                std::cout << kUsage;
+                return 0;
+            }
+            else if (a == "-G" || a == "--gen-matrix")
+                gen = value();
+            else if (a == "-i" || a == "--num-iterations")
+                iterations = static_cast<unsigned>(std::stoul(value()));
+            else if (a == "-s" || a == "--seed")
+                seed = std::stoul(value());
+            else if (a == "-t" || a == "--num-threads")
+                threads = static_cast<unsigned>(std::stoul(value()));
+            else if (a == "--channel")
+                channel = value();
+            else if (a == "--decoding")
+                decoding = value();
+            else if (a == "--max-frames")
+                max_frames = std::stoul(value());
+            else if (a == "--frame-error-count")
+                fec = std::stoul(value());
+            else if (a == "--no-early-term")
+                no_early = true;
+            else if (a == "--device")
+                device = std::stoi(value());
+            else if (a == "--bec-compat")
+                bec_compat = true;
+            else if (a.size() > 1 && a[0] == '-' && !(std::isdigit(static_cast<unsigned char>(a[1])) || a[1] == '.'))
+                throw std::runtime_error("Unknown argument: " + a);
+            else
+                pos.push_back(a); // negative numbers are positional (snr range)
+        }
+        if (pos.size() != 5)
+            throw std::runtime_error("expected: codefile output-file MIN MAX STEP");
+    }
+    catch (const std::exception &e)
+    {
+        fail(e.what());
+    }
+    double range[3];
+    try
+    {
+        for (int i = 0; i < 3; ++i)
+            range[i] = std::stod(pos[2 + i]);
+    }
+    catch (const std::exception &)
+    {
+        fail("snr-range must be three numbers");
+    }
+    if (range[0] > range[1])
+        fail("snr min > snr max"); // sim_cpu.cpp:29
+
+    ldpc_hip_ctx *ctx = ldpc_hip_create(pos[0].c_str(), gen.c_str(), device);
+    if (!ctx)
+    {
+        std::cout << "Error: ldpc_code(): " << ldpc_hip_last_error() << std::endl; // ldpc.cpp:16-20
+        return EXIT_FAILURE;
+    }
+    ldpc_hip_set_bec_compat(ctx, bec_compat);
+    int64_t info[10];
+    ldpc_hip_code_info(ctx, info);
+
+    const char *bar = "========================================================================================";
+    std::cout << bar << std::endl;
+    std::cout << "Parity-Check Matrix: " << pos[0] << std::endl;
+    std::cout << "Generator Matrix: " << gen << std::endl;
+    std::cout << ldpc_hip_describe(ctx) << std::endl;
+    std::cout << bar << std::endl;
+    std::cout << "== Decoder Parameters\n";
+    std::cout << " Type: " << decoding << "\n Iterations: " << iterations << "\n Early Termination: " << !no_early << "\n";
+    std::cout << "== Channel Parameters\n";
+    std::cout << " Type: " << channel << "\n Seed: " << seed << "\n Range: Min: " << range[0] << ", Max: " << range[1]
+              << ", Step: " << range[2] << "\n";
+    std::cout << "== Simulation Parameters\n";
+    std::cout << " Threads: " << threads << "\n FEC: " << fec << "\n Max Frames: " << max_frames
+              << "\n Output File: " << pos[1] << "\n";
+    std::cout << std::endl << bar << std::endl;
+
+    decoder_param dp{!no_early, iterations, decoding.c_str()};
+    channel_param cp{seed, {range[0], range[1], range[2]}, channel.c_str()};
+    simulation_param sp{threads, max_frames, fec, pos[1].c_str()};
+    bool stop = false;
+    int rc = ldpc_hip_simulate(ctx, dp, cp, sp, nullptr, nullptr, &stop, /*cli_output=*/1);
+    if (rc < 0)
+    {
+        std::cout << "Error: ldpc_sim::ldpc_sim() " << ldpc_hip_last_error() << std::endl;
+        ldpc_hip_destroy(ctx);
+        return EXIT_FAILURE;
+    }
+    ldpc_hip_destroy(ctx);
+    return 0;
+}

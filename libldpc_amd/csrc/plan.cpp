@@ -73,8 +73,8 @@ Plan build_plan(const LdpcCode &code)
     p.rank_col.resize(p.nc), p.col_rank.resize(p.nc);
     for (int r = 0; r < p.nc; ++r)
     {
-        p.rank_col[r] = static_cast<uint16_t>(cols[r]);
-        p.col_rank[cols[r]] = static_cast<uint16_t>(r);
+        p.rank_col[r] = static_cast<uint32_t>(cols[r]);
+        p.col_rank[cols[r]] = static_cast<uint32_t>(r);
     }
     std::vector<int> vn_cost;
     for (int i = 0; i < p.nc;)
@@ -82,19 +82,19 @@ Plan build_plan(const LdpcCode &code)
         int d = cdeg(cols[i]), j = i;
         while (j < p.nc && j - i < kWaveSize && cdeg(cols[j]) == d)
             ++j;
-        VnBlock b{static_cast<uint32_t>(p.vn_slot.size()), static_cast<uint16_t>(i), static_cast<uint16_t>(j - i),
-                  static_cast<uint16_t>(d), 0};
+        VnBlock b{static_cast<uint32_t>(p.vn_slot.size()), static_cast<uint32_t>(i), static_cast<uint16_t>(j - i),
+                  static_cast<uint16_t>(d)};
         for (int k = 0; k < d; ++k)
             for (int l = 0; l < j - i; ++l)
-                p.vn_slot.push_back(static_cast<uint16_t>(p.edge_slot[H.cedge[H.cptr[cols[i + l]] + k]]));
+                p.vn_slot.push_back(p.edge_slot[H.cedge[H.cptr[cols[i + l]] + k]]);
         p.vn_blocks.push_back(b);
         vn_cost.push_back(2 * d + 2);
         i = j;
     }
-    p.rank_slot0.assign(p.nc, 0xFFFF);
+    p.rank_slot0.assign(p.nc, kNoSlot);
     for (int r = 0; r < p.nc; ++r)
         if (cdeg(cols[r]) > 0)
-            p.rank_slot0[r] = static_cast<uint16_t>(p.edge_slot[H.cedge[H.cptr[cols[r]]]]);
+            p.rank_slot0[r] = p.edge_slot[H.cedge[H.cptr[cols[r]]]];
     if (p.vn_slot.empty())
         p.vn_slot.push_back(0);
 
@@ -115,23 +115,10 @@ Plan build_plan(const LdpcCode &code)
 
     // ---- LDS footprint of one frame: messages (f64) + input LLRs (f64) + per-slot hard bits ----
     p.lds_bytes = static_cast<size_t>(8) * p.nnz + static_cast<size_t>(8) * p.nc + ((p.nnz + 15) / 16) * 16 + 16;
-    p.lds_ok = code.min_cn_degree() >= 2 && p.max_cn_degree <= kMaxLdsCnDegree && p.nnz < 65536 &&
-               p.nc < 65536 && p.lds_bytes <= 160 * 1024;
-
-    // ---- plain CSR/CSC for the HBM-resident decoder ----
-    p.row_ptr.assign(H.rptr.begin(), H.rptr.end());
-    p.row_edge_col.resize(p.nnz);
-    std::vector<uint32_t> edge_rowmajor(p.nnz); // file edge -> row-major position
-    for (int r = 0; r < p.mc; ++r)
-        for (int k = H.rptr[r]; k < H.rptr[r + 1]; ++k)
-        {
-            p.row_edge_col[k] = static_cast<uint32_t>(H.rcol[k]);
-            edge_rowmajor[H.redge[k]] = static_cast<uint32_t>(k);
-        }
-    p.col_ptr.assign(H.cptr.begin(), H.cptr.end());
-    p.col_edge.resize(p.nnz);
-    for (int k = 0; k < p.nnz; ++k)
-        p.col_edge[k] = edge_rowmajor[H.cedge[k]];
+    p.lds_ok = code.min_cn_degree() >= 2 && p.max_cn_degree <= kMaxLdsCnDegree && p.lds_bytes <= 160 * 1024 &&
+               p.cn_blocks.size() < 0xFFFF && p.vn_blocks.size() < 0xFFFF;
+    p.hbm_ok = code.min_cn_degree() >= 2 && p.max_cn_degree <= kMaxCnDegree && p.cn_blocks.size() < 0xFFFF &&
+               p.vn_blocks.size() < 0xFFFF;
     return p;
 }
 

@@ -26,7 +26,9 @@ namespace ldpc_amd
 {
 
 constexpr int kWaveSize = 64;
-constexpr int kMaxLdsCnDegree = 8;  // widest check node the register-resident CN update is built for
+constexpr int kMaxLdsCnDegree = 8;  // widest check node of the LDS-resident decoder's register CN update
+constexpr int kMaxCnDegree = 16;    // widest check node of the memory-resident decoder
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr int kDecodeWaves = 4;     // waves per workgroup of the LDS-resident decoder
 
 struct CnBlock
@@ -39,10 +41,9 @@ struct CnBlock
 struct VnBlock
 {
     uint32_t idx_off; // into vn_slot: [idx_off + p*count + lane]
-    uint16_t first;   // first VN rank
+    uint32_t first;   // first VN rank
     uint16_t count;
     uint16_t degree;
-    uint16_t pad;
 };
 
 // Host-side plan (uploaded verbatim by the engine)
@@ -52,23 +53,20 @@ struct Plan
     int max_cn_degree = 0, max_vn_degree = 0;
     std::vector<CnBlock> cn_blocks;
     std::vector<VnBlock> vn_blocks;
-    std::vector<uint16_t> vn_slot;   // slot of the p-th edge (column file order) of each VN
+    std::vector<uint32_t> vn_slot;   // slot of the p-th edge (column file order) of each VN
     std::vector<uint16_t> cn_work;   // [kDecodeWaves][cn_work_stride] block ids, 0xFFFF = none
     std::vector<uint16_t> vn_work;   // [kDecodeWaves][vn_work_stride]
     int cn_work_stride = 0, vn_work_stride = 0;
-    std::vector<uint16_t> col_rank;  // column -> VN rank
-    std::vector<uint16_t> rank_col;  // VN rank -> column
-    std::vector<uint16_t> tx_rank;   // transmitted index i -> rank of bit_pos[i]
+    std::vector<uint32_t> col_rank;  // column -> VN rank
+    std::vector<uint32_t> rank_col;  // VN rank -> column
+    std::vector<uint32_t> tx_rank;   // transmitted index i -> rank of bit_pos[i]
     std::vector<uint8_t> rank_kind;  // 0 transmitted, 1 punctured, 2 shortened
-    std::vector<uint16_t> rank_slot0; // slot of the VN's first edge, 0xFFFF for an isolated VN
+    std::vector<uint32_t> rank_slot0; // slot of the VN's first edge, kNoSlot for an isolated VN
     std::vector<uint32_t> edge_slot; // file-order edge -> slot (tests / debugging)
     std::vector<uint32_t> cn_rank_row; // slot-space CN order -> original row (tests)
     size_t lds_bytes = 0;            // dynamic LDS the LDS-resident kernel needs per frame
     bool lds_ok = false;             // fits the LDS-resident kernel's limits
-
-    // HBM-resident (large code) tables: plain CSR/CSC in file order
-    std::vector<uint32_t> row_ptr, row_edge_col;  // [mc+1], [nnz] column of each row edge (file order)
-    std::vector<uint32_t> col_ptr, col_edge;      // [nc+1], [nnz] row-major edge id of each column edge
+    bool hbm_ok = false;             // within the memory-resident kernel's limits
 };
 
 Plan build_plan(const LdpcCode &code);

@@ -47,8 +47,11 @@ int run_simulation(Engine &eng, const SimRequest &rq, sim_results_t *results, ui
     {
         uint64_t bec = 0, fec = 0, frames = 0, iters = 0;
         auto t_start = clock::now();
-        eng.stream_begin(rq.channel, rq.seed, xs[i]);
-        uint64_t batch = rq.first_batch;
+        // the reference builds its channel objects once per run (ldpcsim.cpp:29-75): the info-word stream
+        // and the accumulated codeword carry over from one channel point to the next
+        eng.stream_begin(rq.channel, rq.seed, xs[i], /*fresh=*/i == 0);
+        const uint64_t max_batch = std::min<uint64_t>(rq.max_batch, eng.max_sub_batch());
+        uint64_t batch = std::min<uint64_t>(rq.first_batch, max_batch);
         bool go = true;
         while (go)
         {
@@ -56,8 +59,10 @@ int run_simulation(Engine &eng, const SimRequest &rq, sim_results_t *results, ui
             BatchOut out;
             out.iters = it_buf.data(), out.bit_errors = be_buf.data();
             eng.stream_decode(rq.dec, batch, out, nullptr);
+            uint64_t used = 0;
             for (uint64_t f = 0; f < batch && go; ++f)
             {
+                used = f + 1;
                 iters += it_buf[f]; // accumulated for every decoded frame (ldpcsim.cpp:175-176)
                 if (fec < rq.min_fec)
                 {
@@ -103,17 +108,19 @@ int run_simulation(Engine &eng, const SimRequest &rq, sim_results_t *results, ui
                 }
                 go = fec < rq.min_fec && frames < rq.max_frames && !*stop_flag; // ldpcsim.cpp:255
             }
+            if (!go) // frames decoded past the stopping frame never happened as far as the encoder is concerned
+                eng.stream_rewind_encoder(batch - used, nullptr);
             // next batch: enough frames for the errors still missing at the observed rate, within bounds
             if (go)
             {
-                uint64_t want = rq.max_batch;
+                uint64_t want = max_batch;
                 if (fec > 0)
                 {
                     double per_err = static_cast<double>(frames) / static_cast<double>(fec);
                     want = static_cast<uint64_t>(per_err * static_cast<double>(rq.min_fec - fec) * 1.25) + 1;
                 }
                 want = std::min<uint64_t>(want, rq.max_frames - frames);
-                batch = std::clamp<uint64_t>(want, std::min(rq.first_batch, rq.max_batch), rq.max_batch);
+                batch = std::clamp<uint64_t>(want, std::min(rq.first_batch, max_batch), max_batch);
             }
         }
         if (rq.cli_output)

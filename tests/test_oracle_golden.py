@@ -120,3 +120,15 @@ def test_det_mode_within_tolerance_of_libm(codes, golden_frames):
     assert np.array_equal(r["hard"], golden_frames["awgn_bp_m4/hard"])
     assert np.max(np.abs(r["llr_in"] - golden_frames["awgn_bp_m4/llr_in"])) < 1e-12
     assert np.max(np.abs(r["llr_out"] - golden_frames["awgn_bp_m4/llr_out"])) < 1e-5
+
+
+def test_8k_code_frames_bit_exact(h8k_file, golden_8k, golden_sim):
+    """config 4: (3,6)-regular nc=8192 — oracle == reference on AWGN/BSC/BEC frames."""
+    code = orc.Code(h8k_file)
+    assert (code.nc, code.mc, code.nnz, code.max_degree) == (8192, 4096, 24576, 6)
+    for name, (ch, dec, it, early, seed, x, skip, cnt) in golden_sim["h8k"]["cases"].items():
+        r = code.run_frames(ch, x, seed=seed, skip=skip, count=cnt, min_sum=(dec == "BP_MS"), early_term=bool(early),
+                            iters=it, bec_compat=True)
+        for k in ("iters", "bit_errors", "hard", "llr_in", "llr_out"):
+            ref = golden_8k[f"{name}/{k}"]
+            assert np.array_equal(ref, r[k].astype(ref.dtype)), f"{name}/{k}"

@@ -86,10 +86,9 @@ def main():
 
     import torch
     import libldpc_amd
+    from libldpc_amd import shard
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = shard.rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -110,19 +109,15 @@ def main():
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
 
     # rank r owns the contiguous frame range [r*(W+K)*B, (r+1)*(W+K)*B) of the single stream (seed 0)
+    first, _ = shard.frame_range(rank, world, (W + K) * B)
     dec.stream_begin("AWGN", 0, SNR_DB)
-    if rank:
-        dec.stream_skip(rank * (W + K) * B, stream)
+    if first:
+        dec.stream_skip(first, stream)
 
     def step():
         dec.stream_decode(B, early_term=early, iterations=ITERS, decoding=args.decoding, want=(), out=out, stream=stream)
-        it = iters_d.to(torch.int64)
-        conv = it < ITERS if early else torch.zeros_like(it, dtype=torch.bool)
-        c = torch.stack([torch.tensor(B, device=dev, dtype=torch.int64), (be_d > 0).sum(), be_d.sum().to(torch.int64),
-                         it.sum(), conv.sum()])
-        if dist is not None:
-            dist.all_reduce(c)  # the one collective of the path: counters over xGMI
-        return c
+        c = shard.counters_from_outputs(torch, iters_d, be_d, ITERS, early)
+        return shard.reduce_counters(c, dist)  # the one collective of the path: 5 x int64 over xGMI
 
     tot = torch.zeros(5, dtype=torch.int64, device=dev)
     for _ in range(W):  # same ops as the timed loop, so every kernel's code object is loaded beforehand

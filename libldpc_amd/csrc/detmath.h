@@ -247,4 +247,40 @@ DM_FN double dm_boxplus(double x, double y)
     return m + dm_boxplus_log(num / den);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Check-node form of the box-plus: exponentials shared between the box-pluses of one check node.
+ *
+ * A degree-d check node evaluates 3(d-2) box-pluses over only 3(d-2) distinct operands (the d inputs and
+ * the forward/backward partial results that are used again).  With E(v) = e^-|v| computed once per
+ * operand, and with a = |x| + |y|, b = ||x| - |y||:
+ *
+ *     e^-a = E(x) E(y)                         e^-b = Emin / Emax      (Emax = max(E(x), E(y)) ...)
+ *     (1 + e^-a) / (1 + e^-b) = Emax (1 + E(x)E(y)) / (Emax + Emin)          =: q   in (1/2, 1]
+ *
+ * and jacobian(x,y) = s (min(|x|,|y|) + log q), s = sign(x) sign(y): for equal signs the reference's
+ * numerator holds e^-a, for opposite signs the fraction is inverted and log(1/q) = -log q.  This is the
+ * reference's expression (decoder.h:12-15) with e^-|x+-y| rewritten through e^-|x| e^-|y|; one exponential
+ * per box-plus instead of two, still one division and one logarithm.
+ *
+ * The rewrite needs E(x), E(y) to be normal numbers: callers use it only while every operand of the check
+ * node satisfies |v| <= DM_SHARED_LIMIT (box-plus results never exceed their smaller operand in magnitude)
+ * and fall back to dm_boxplus for the whole node otherwise (e.g. two shortened bits, LLR 99999.9).
+ * ------------------------------------------------------------------------------------------------ */
+#define DM_SHARED_LIMIT 600.0
+
+DM_FN double dm_boxplus_shared(double x, double y, double ex, double ey)
+{
+    double mn = __builtin_fmin(__builtin_fabs(x), __builtin_fabs(y));
+    uint64_t sgn = (dm_bits(x) ^ dm_bits(y)) & 0x8000000000000000ull;
+    double m = dm_from_bits(dm_bits(mn) | sgn);          /* s min(|x|,|y|) */
+    double sd = dm_from_bits(0x3FF0000000000000ull | sgn); /* s as +-1.0 */
+    double p = ex * ey;
+    double emx = __builtin_fmax(ex, ey), emn = __builtin_fmin(ex, ey);
+    double num = DM_FMA(emx, p, emx); /* Emax (1 + P) */
+    double den = emx + emn;
+    double l = dm_boxplus_log(num / den); /* <= 0 */
+    /* s * l, with +0.0 for l == 0 as in the reference, where log(1) = +0 is added to -0.0 */
+    return m + DM_FMA(sd, l, 0.0);
+}
+
 #endif /* LDPC_AMD_DETMATH_H */

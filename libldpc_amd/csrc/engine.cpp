@@ -296,6 +296,7 @@ void Engine::upload_plan()
     };
     const Plan &p = plan_;
     dev_.nc = p.nc, dev_.mc = p.mc, dev_.nnz = p.nnz, dev_.nct = p.nct;
+    dev_.n_bitpos = p.n_bitpos;
     dev_.n_cn_blocks = static_cast<int>(p.cn_blocks.size());
     dev_.n_vn_blocks = static_cast<int>(p.vn_blocks.size());
     dev_.cn_work_stride = p.cn_work_stride, dev_.vn_work_stride = p.vn_work_stride;
@@ -349,7 +350,18 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
     if (profiling_)
         check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), s), "event");
     if (plan_.lds_ok)
-        check(launch_decode_lds(a, p.min_sum, s), "decode (LDS-resident)");
+    {
+        // Input LLRs stay in LDS.  Moving them to memory (LDPC_AMD_LLR_MEM=1) frees room for a fifth resident
+        // frame per CU on the n=1024 code, but the extra memory reads cost what the occupancy gains (measured).
+        bool llr_mem = false;
+        if (const char *e = std::getenv("LDPC_AMD_LLR_MEM"))
+            llr_mem = e[0] == '1';
+        if (llr_mem)
+            a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
+        if (const char *e = std::getenv("LDPC_AMD_LDS_PAD")) // occupancy experiments: extra dynamic LDS per frame
+            a.plan.lds_bytes += static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) & ~15u;
+        check(launch_decode_lds(a, p.min_sum, plan_.max_cn_degree, s), "decode (LDS-resident)");
+    }
     else if (plan_.hbm_ok)
     {
         a.ws_msg = static_cast<double *>(ws_msg_.reserve(8 * n * nnz));
@@ -362,7 +374,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         if (const char *e = std::getenv("LDPC_AMD_FRAMES_PER_CU"))
             frames_per_cu = std::clamp<uint64_t>(std::strtoull(e, nullptr, 10), 1, 8);
         const uint32_t occ_lds = frames_per_cu >= 8 ? 0 : static_cast<uint32_t>((160 * 1024) / (frames_per_cu + 1) + 1024) & ~15u;
-        check(launch_decode_mem(a, p.min_sum, occ_lds, s), "decode (memory-resident)");
+        check(launch_decode_mem(a, p.min_sum, plan_.max_cn_degree, occ_lds, s), "decode (memory-resident)");
     }
     else
         throw std::runtime_error("check-node degree above " + std::to_string(kMaxCnDegree) + " is not supported");

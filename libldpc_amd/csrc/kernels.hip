@@ -42,6 +42,44 @@ __device__ __forceinline__ void cn_update(double *m, int stride)
 #pragma unroll
     for (int j = 0; j < D; ++j)
         v[j] = m[j * stride];
+    if constexpr (!MINSUM)
+    {
+        // sum-product: exponentials shared between the node's box-pluses (detmath.h, dm_boxplus_shared),
+        // valid while every operand is within DM_SHARED_LIMIT; otherwise the direct form below
+        double amax = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            amax = __builtin_fmax(amax, __builtin_fabs(v[j]));
+        if (amax <= DM_SHARED_LIMIT)
+        {
+            double ev[D], eF[D], eB[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                ev[j] = dm_boxplus_exp(__builtin_fabs(v[j]));
+            F[0] = v[0], eF[0] = ev[0];
+            B[D - 1] = v[D - 1], eB[D - 1] = ev[D - 1];
+#pragma unroll
+            for (int j = 1; j < D - 1; ++j)
+            {
+                F[j] = dm_boxplus_shared(F[j - 1], v[j], eF[j - 1], ev[j]);
+                if (j < D - 2) // F[D-2] is only an output
+                    eF[j] = dm_boxplus_exp(__builtin_fabs(F[j]));
+            }
+#pragma unroll
+            for (int j = D - 2; j >= 1; --j)
+            {
+                B[j] = dm_boxplus_shared(B[j + 1], v[j], eB[j + 1], ev[j]);
+                if (j > 1) // B[1] is only an output
+                    eB[j] = dm_boxplus_exp(__builtin_fabs(B[j]));
+            }
+            m[0] = B[1];
+            m[(D - 1) * stride] = F[D - 2];
+#pragma unroll
+            for (int j = 1; j < D - 1; ++j)
+                m[j * stride] = dm_boxplus_shared(F[j - 1], B[j + 1], eF[j - 1], eB[j + 1]);
+            return;
+        }
+    }
     F[0] = v[0];
     B[D - 1] = v[D - 1];
 #pragma unroll
@@ -69,11 +107,18 @@ __device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane)
     case 2: cn_update<2, MINSUM>(m, s); break;
     case 3: cn_update<3, MINSUM>(m, s); break;
     case 4: cn_update<4, MINSUM>(m, s); break;
-    case 5: cn_update<5, MINSUM>(m, s); break;
-    case 6: cn_update<6, MINSUM>(m, s); break;
-    case 7: cn_update<7, MINSUM>(m, s); break;
-    case 8: cn_update<8, MINSUM>(m, s); break;
     default:
+        if constexpr (MAXD > 4)
+        {
+            switch (b.degree)
+            {
+            case 5: cn_update<5, MINSUM>(m, s); break;
+            case 6: cn_update<6, MINSUM>(m, s); break;
+            case 7: cn_update<7, MINSUM>(m, s); break;
+            case 8: cn_update<8, MINSUM>(m, s); break;
+            default: break;
+            }
+        }
         if constexpr (MAXD > 8)
         {
             switch (b.degree)
@@ -107,7 +152,10 @@ __device__ __forceinline__ int wave_sum(int v)
 //   lane, then by its own VN lane), llr[nc] f64 (VN rank order), hb[nnz] u8 (hard decision of the
 //   edge's VN, read back by the CN lanes for the syndrome).
 // ---------------------------------------------------------------------------------------------
-template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT>
+// MAXD = widest check node the instantiation handles (4, 8 or 16): the register allocation of a kernel is
+// that of its widest CN update, so narrow codes get a leaner kernel.
+// LLR_IN_LDS = false keeps the input LLRs (read once per VN per iteration) in memory instead of LDS.
+template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, bool LLR_IN_LDS>
 __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 {
     extern __shared__ double lds[];
@@ -120,8 +168,16 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
     if constexpr (LDS_RESIDENT)
     {
         msg = lds;
-        llr = lds + nnz;
-        hb = reinterpret_cast<uint8_t *>(llr + nc);
+        if constexpr (LLR_IN_LDS)
+        {
+            llr = lds + nnz;
+            hb = reinterpret_cast<uint8_t *>(llr + nc);
+        }
+        else
+        {
+            llr = a.ws_llr + frame * nc;
+            hb = reinterpret_cast<uint8_t *>(lds + nnz);
+        }
     }
     else
     {
@@ -129,7 +185,6 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
         llr = a.ws_llr + frame * nc;
         hb = a.ws_hb + frame * nnz;
     }
-    constexpr int MAXD = LDS_RESIDENT ? kMaxLdsCnDegree : kMaxCnDegree;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -155,6 +210,8 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
                 llr[r] = 0.0; // punctured = erasure
             else if (k == 2)
                 llr[r] = a.shorten_llr;
+            else if (k == 3)
+                llr[r] = 0.0; // never written by the channel: keeps the decoder's initial zero
         }
         if (a.mode == kModeAwgn)
         {
@@ -316,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
     if (a.bit_errors)
     {
         int err = 0;
-        for (int i = tid; i < nct; i += kThreads)
+        for (int i = tid; i < P.n_bitpos; i += kThreads) // the reference walks the whole bit_pos vector
         {
             int est = hard_of_rank(P.tx_rank[i]);
             int tx = cw ? static_cast<int>(cw[P.bit_pos[i]]) : 0;
@@ -374,6 +431,8 @@ __global__ __launch_bounds__(kThreads) void bec_kernel(const BecArgs a)
                 uint32_t col = P.rank_col[r];
                 sym[r] = (col < static_cast<uint32_t>(nct) && cw) ? cw[P.bit_pos[col]] : 0;
             }
+            else if (k == 3)
+                sym[r] = 0; // never written by the channel: the decoder's initial zero, a known 0 bit
         }
         const uint64_t *raw = a.raw + frame * static_cast<uint64_t>(nct);
         for (int i = tid; i < nct; i += kThreads)
@@ -543,7 +602,7 @@ __global__ __launch_bounds__(kThreads) void bec_kernel(const BecArgs a)
     if (a.bit_errors)
     {
         int err = 0;
-        for (int i = tid; i < nct; i += kThreads)
+        for (int i = tid; i < P.n_bitpos; i += kThreads)
         {
             int r = P.tx_rank[i];
             err += hard_of_rank(r) != static_cast<int>(cw_of_rank(r));
@@ -629,17 +688,17 @@ __global__ __launch_bounds__(256) void encode_cw_kernel(const EncodeArgs a, uint
     }
 }
 
-template <bool LDS_RESIDENT>
+template <bool LDS_RESIDENT, int MAXD, bool LLR_IN_LDS>
 int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *stream)
 {
-    if (a.n_frames == 0)
-        return hipSuccess;
     const bool want_llr = a.llr_out != nullptr;
     void (*k)(const DecodeArgs) = nullptr;
     if (min_sum)
-        k = want_llr ? decode_kernel<true, true, LDS_RESIDENT> : decode_kernel<true, false, LDS_RESIDENT>;
+        k = want_llr ? decode_kernel<true, true, LDS_RESIDENT, MAXD, LLR_IN_LDS>
+                     : decode_kernel<true, false, LDS_RESIDENT, MAXD, LLR_IN_LDS>;
     else
-        k = want_llr ? decode_kernel<false, true, LDS_RESIDENT> : decode_kernel<false, false, LDS_RESIDENT>;
+        k = want_llr ? decode_kernel<false, true, LDS_RESIDENT, MAXD, LLR_IN_LDS>
+                     : decode_kernel<false, false, LDS_RESIDENT, MAXD, LLR_IN_LDS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));
     if (e != hipSuccess)
@@ -651,16 +710,34 @@ int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *s
 
 } // namespace
 
-int launch_decode_lds(const DecodeArgs &a, bool min_sum, void *stream)
+int launch_decode_lds(const DecodeArgs &a, bool min_sum, int max_cn_degree, void *stream)
 {
-    return launch_decode<true>(a, min_sum, a.plan.lds_bytes, stream);
+    if (a.n_frames == 0)
+        return hipSuccess;
+    const bool llr_mem = a.ws_llr != nullptr;
+    const uint32_t lds = a.plan.lds_bytes - (llr_mem ? 8u * static_cast<uint32_t>(a.plan.nc) : 0u);
+    if (max_cn_degree <= 4)
+        return llr_mem ? launch_decode<true, 4, false>(a, min_sum, lds, stream)
+                       : launch_decode<true, 4, true>(a, min_sum, lds, stream);
+    if (max_cn_degree <= 8)
+        return llr_mem ? launch_decode<true, 8, false>(a, min_sum, lds, stream)
+                       : launch_decode<true, 8, true>(a, min_sum, lds, stream);
+    return hipErrorInvalidValue;
 }
 
-int launch_decode_mem(const DecodeArgs &a, bool min_sum, uint32_t occupancy_lds, void *stream)
+int launch_decode_mem(const DecodeArgs &a, bool min_sum, int max_cn_degree, uint32_t occupancy_lds, void *stream)
 {
+    if (a.n_frames == 0)
+        return hipSuccess;
     if (!a.ws_msg || !a.ws_llr || !a.ws_hb)
         return hipErrorInvalidValue;
-    return launch_decode<false>(a, min_sum, occupancy_lds, stream);
+    if (max_cn_degree <= 4)
+        return launch_decode<false, 4, false>(a, min_sum, occupancy_lds, stream);
+    if (max_cn_degree <= 8)
+        return launch_decode<false, 8, false>(a, min_sum, occupancy_lds, stream);
+    if (max_cn_degree <= 16)
+        return launch_decode<false, 16, false>(a, min_sum, occupancy_lds, stream);
+    return hipErrorInvalidValue;
 }
 
 int launch_bec(const BecArgs &a, void *stream)

@@ -12,6 +12,7 @@ namespace ldpc_amd
 struct DevPlan
 {
     int nc, mc, nnz, nct;
+    int n_bitpos;
     int n_cn_blocks, n_vn_blocks;
     int cn_work_stride, vn_work_stride;
     const CnBlock *cn_blocks;
@@ -24,7 +25,7 @@ struct DevPlan
     const uint32_t *tx_rank;
     const uint8_t *rank_kind;
     const uint32_t *rank_slot0;
-    const int *bit_pos; // [nct] transmitted index -> column
+    const int *bit_pos; // [n_bitpos] transmitted index -> column
     uint32_t lds_bytes;
 };
 
@@ -88,10 +89,11 @@ struct BecArgs
 };
 
 // All launchers enqueue on `stream` (hipStream_t passed as void*) and return a hipError_t as int.
-int launch_decode_lds(const DecodeArgs &a, bool min_sum, void *stream);
+// LDS-resident decoder; a.ws_llr != nullptr keeps the input LLRs in memory instead of LDS
+int launch_decode_lds(const DecodeArgs &a, bool min_sum, int max_cn_degree, void *stream);
 // memory-resident variant for codes whose messages do not fit LDS (a.ws_* must be set); occupancy_lds
 // bytes of dynamic LDS are requested only to bound the number of resident frames per CU
-int launch_decode_mem(const DecodeArgs &a, bool min_sum, uint32_t occupancy_lds, void *stream);
+int launch_decode_mem(const DecodeArgs &a, bool min_sum, int max_cn_degree, uint32_t occupancy_lds, void *stream);
 int launch_bec(const BecArgs &a, void *stream);
 
 // ---- mt19937_64 on the device ----

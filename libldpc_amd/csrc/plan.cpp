@@ -109,9 +109,18 @@ Plan build_plan(const LdpcCode &code)
     for (int c : code.shorten) // the reference applies shorten after puncture (channel.cpp:73-86)
         if (c >= 0 && c < p.nc)
             p.rank_kind[p.col_rank[c]] = 2;
+    // nct = nc - |puncture| - |shorten| (ldpc.h:55) while bit_pos drops each listed column once: a column in
+    // both lists leaves bit_pos longer than nct.  The channel then never writes the LLR of the surplus
+    // positions (they keep the zero the decoder was constructed with) but the error count still visits them.
+    p.n_bitpos = static_cast<int>(code.bit_pos.size());
+    p.nct = std::min(p.nct, p.n_bitpos);
     p.tx_rank.resize(code.bit_pos.size());
     for (size_t i = 0; i < code.bit_pos.size(); ++i)
+    {
         p.tx_rank[i] = p.col_rank[code.bit_pos[i]];
+        if (static_cast<int>(i) >= p.nct)
+            p.rank_kind[p.tx_rank[i]] = 3;
+    }
 
     // ---- LDS footprint of one frame: messages (f64) + input LLRs (f64) + per-slot hard bits ----
     p.lds_bytes = static_cast<size_t>(8) * p.nnz + static_cast<size_t>(8) * p.nc + ((p.nnz + 15) / 16) * 16 + 16;

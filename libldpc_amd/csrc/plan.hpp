@@ -50,6 +50,7 @@ struct VnBlock
 struct Plan
 {
     int nc = 0, mc = 0, nnz = 0, nct = 0;
+    int n_bitpos = 0; // entries of bit_pos (> nct when a column is both punctured and shortened)
     int max_cn_degree = 0, max_vn_degree = 0;
     std::vector<CnBlock> cn_blocks;
     std::vector<VnBlock> vn_blocks;
@@ -60,7 +61,7 @@ struct Plan
     std::vector<uint32_t> col_rank;  // column -> VN rank
     std::vector<uint32_t> rank_col;  // VN rank -> column
     std::vector<uint32_t> tx_rank;   // transmitted index i -> rank of bit_pos[i]
-    std::vector<uint8_t> rank_kind;  // 0 transmitted, 1 punctured, 2 shortened
+    std::vector<uint8_t> rank_kind;  // 0 transmitted, 1 punctured, 2 shortened, 3 never written by the channel
     std::vector<uint32_t> rank_slot0; // slot of the VN's first edge, kNoSlot for an isolated VN
     std::vector<uint32_t> edge_slot; // file-order edge -> slot (tests / debugging)
     std::vector<uint32_t> cn_rank_row; // slot-space CN order -> original row (tests)

@@ -43,6 +43,7 @@ struct orc_code
     int *punct, *shrt;
     int *bit_pos;
     int nct, mct, kct, kc, max_degree;
+    int n_bitpos; /* entries of bit_pos: > nct when a column is both punctured and shortened */
 };
 
 static void spm_free(spm *m)
@@ -198,6 +199,7 @@ orc_code *orc_code_load(const char *pc_file, const char *gen_file)
             continue;
         c->bit_pos[nb++] = i;
     }
+    c->n_bitpos = nb;
     /* ldpc.h:47-59 (note: nct is computed from the list sizes, not from bit_pos) */
     c->kc = c->H.cols - c->H.rows;
     c->nct = c->H.cols - c->npunct - c->nshort;
@@ -245,6 +247,7 @@ void orc_code_edges(const orc_code *c, int *er, int *ec)
     memcpy(ec, c->H.ecol, sizeof(int) * c->H.nnz);
 }
 void orc_code_bit_pos(const orc_code *c, int *b) { memcpy(b, c->bit_pos, sizeof(int) * c->nct); }
+int orc_code_n_bitpos(const orc_code *c) { return c->n_bitpos; }
 void orc_code_puncture(const orc_code *c, int *p) { memcpy(p, c->punct, sizeof(int) * c->npunct); }
 void orc_code_shorten(const orc_code *c, int *s) { memcpy(s, c->shrt, sizeof(int) * c->nshort); }
 
@@ -362,6 +365,46 @@ static void dec_free(dec_t *d)
     free(d->v2c), free(d->c2v), free(d->F), free(d->B), free(d->llr_in), free(d->llr_out), free(d->co);
 }
 
+/*
+ * ORC_MATH_DET only: the same forward/backward recursion (decoder.cpp:31-44) with the exponentials shared
+ * between the box-pluses of the node (detmath.h, dm_boxplus_shared) — the arithmetic the HIP kernel runs.
+ * Returns 0 (nothing done) when an operand exceeds DM_SHARED_LIMIT; the caller then takes the direct
+ * dm_boxplus path for this node, as the kernel does.  F[cw-1] and B[0], which the reference computes and
+ * never reads, are not evaluated.
+ */
+static int cn_update_det_shared(dec_t *d, const int *cn, int cw)
+{
+    enum { MAXD = 64 };
+    double v[MAXD], ev[MAXD], F[MAXD], eF[MAXD], B[MAXD], eB[MAXD];
+    if (cw > MAXD || cw < 2)
+        return 0;
+    for (int j = 0; j < cw; ++j)
+    {
+        v[j] = d->v2c[cn[j]];
+        if (!(fabs(v[j]) <= DM_SHARED_LIMIT))
+            return 0;
+    }
+    for (int j = 0; j < cw; ++j)
+        ev[j] = dm_boxplus_exp(fabs(v[j]));
+    F[0] = v[0], eF[0] = ev[0];
+    B[cw - 1] = v[cw - 1], eB[cw - 1] = ev[cw - 1];
+    for (int j = 1; j < cw - 1; ++j)
+    {
+        F[j] = dm_boxplus_shared(F[j - 1], v[j], eF[j - 1], ev[j]);
+        eF[j] = dm_boxplus_exp(fabs(F[j]));
+    }
+    for (int j = cw - 2; j >= 1; --j)
+    {
+        B[j] = dm_boxplus_shared(B[j + 1], v[j], eB[j + 1], ev[j]);
+        eB[j] = dm_boxplus_exp(fabs(B[j]));
+    }
+    d->c2v[cn[0]] = B[1];
+    d->c2v[cn[cw - 1]] = F[cw - 2];
+    for (int j = 1; j < cw - 1; ++j)
+        d->c2v[cn[j]] = dm_boxplus_shared(F[j - 1], B[j + 1], eF[j - 1], eB[j + 1]);
+    return 1;
+}
+
 /* decoder.h:47-64 */
 static int is_codeword(const dec_t *d)
 {
@@ -392,6 +435,8 @@ static int dec_decode(dec_t *d)
             int cw = H->rptr[i + 1] - H->rptr[i];
             const int *cn = H->redge + H->rptr[i];
             double *F = d->F, *B = d->B;
+            if (d->cn == jacobian_det && cn_update_det_shared(d, cn, cw))
+                continue;
             F[0] = d->v2c[cn[0]];
             B[cw - 1] = d->v2c[cn[cw - 1]];
             for (int j = 1; j < cw; ++j)
@@ -821,7 +866,7 @@ static uint32_t count_bit_errors(const orc_chan *ch) /* ldpcsim.cpp:184-188 */
     const orc_code *c = ch->code;
     const uint8_t *est = orc_chan_estimate(ch);
     uint32_t n = 0;
-    for (int i = 0; i < c->nct; ++i)
+    for (int i = 0; i < c->n_bitpos; ++i) /* the reference iterates the whole bit_pos vector */
         n += est[c->bit_pos[i]] != ch->cw[c->bit_pos[i]];
     return n;
 }

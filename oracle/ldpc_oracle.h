@@ -44,6 +44,7 @@ int orc_code_kct(const orc_code *c);
 int orc_code_max_degree(const orc_code *c);
 int orc_code_num_puncture(const orc_code *c);
 int orc_code_num_shorten(const orc_code *c);
+int orc_code_n_bitpos(const orc_code *c); /* == nct unless a column is both punctured and shortened */
 int orc_code_has_G(const orc_code *c);
 int orc_code_g_rows(const orc_code *c);
 int orc_code_g_cols(const orc_code *c);

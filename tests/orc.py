@@ -169,6 +169,14 @@ class Code:
         return out
 
 
+def shortened_variant(path):
+    """h.txt with `shorten [4]: 130 290 0 1` (130 and 290 are two of the three neighbours of check node 0)."""
+    txt = open(H_TXT).read()
+    assert "shorten [0]: " in txt
+    open(path, "w").write(txt.replace("shorten [0]: ", "shorten [4]: 130 290 0 1"))
+    return path
+
+
 def mt64_stream(seed, n):
     out = np.zeros(n, np.uint64)
     lib().orc_mt64_stream(seed, n, _p(out))

@@ -132,3 +132,16 @@ def test_8k_code_frames_bit_exact(h8k_file, golden_8k, golden_sim):
         for k in ("iters", "bit_errors", "hard", "llr_in", "llr_out"):
             ref = golden_8k[f"{name}/{k}"]
             assert np.array_equal(ref, r[k].astype(ref.dtype)), f"{name}/{k}"
+
+
+def test_shortened_code_frames_bit_exact(hshort_file, golden_frames, golden_sim):
+    """shortening (LLR 99999.9 / delta / known symbol) incl. two shortened bits on one check node"""
+    code = orc.Code(hshort_file)
+    # column 290 is punctured AND shortened: nct = 1152 - 128 - 4 counts it twice (ldpc.h:55)
+    assert (code.nct, code.kct, code.num_shorten) == (1020, 124, 4)
+    for name, (ch, dec, it, early, seed, x, skip, cnt) in golden_sim["short_cases"].items():
+        r = code.run_frames(ch, x, seed=seed, skip=skip, count=cnt, min_sum=(dec == "BP_MS"), early_term=bool(early),
+                            iters=it, bec_compat=True)
+        for k in ("iters", "bit_errors", "hard", "llr_in", "llr_out", "codeword"):
+            ref = golden_frames[f"short/{name}/{k}"]
+            assert np.array_equal(ref, r[k].astype(ref.dtype)), f"{name}/{k}"

@@ -248,39 +248,42 @@ DM_FN double dm_boxplus(double x, double y)
 }
 
 /* ------------------------------------------------------------------------------------------------
- * Check-node form of the box-plus: exponentials shared between the box-pluses of one check node.
+ * Check-node form of the box-plus: the forward/backward recursion carried in the variable E = e^-|L|.
  *
- * A degree-d check node evaluates 3(d-2) box-pluses over only 3(d-2) distinct operands (the d inputs and
- * the forward/backward partial results that are used again).  With E(v) = e^-|v| computed once per
- * operand, and with a = |x| + |y|, b = ||x| - |y||:
+ * With E(v) = e^-|v| and s(v) = sign(v), the reference's box-plus (decoder.h:12-15)
  *
- *     e^-a = E(x) E(y)                         e^-b = Emin / Emax      (Emax = max(E(x), E(y)) ...)
- *     (1 + e^-a) / (1 + e^-b) = Emax (1 + E(x)E(y)) / (Emax + Emin)          =: q   in (1/2, 1]
+ *     x [+] y = s(x) s(y) min(|x|,|y|) + log( (1 + e^-|x+y|) / (1 + e^-|x-y|) )
  *
- * and jacobian(x,y) = s (min(|x|,|y|) + log q), s = sign(x) sign(y): for equal signs the reference's
- * numerator holds e^-a, for opposite signs the fraction is inverted and log(1/q) = -log q.  This is the
- * reference's expression (decoder.h:12-15) with e^-|x+-y| rewritten through e^-|x| e^-|y|; one exponential
- * per box-plus instead of two, still one division and one logarithm.
+ * is the same real function as        |x [+] y| = -log( (E(x) + E(y)) / (1 + E(x) E(y)) ),
+ *                                   s(x [+] y) = s(x) s(y)
+ * (write a = |x|, b = |y|: min(a,b) + log((1+e^-(a+b))/(1+e^-|a-b|)) = log((1+e^-(a+b))/(e^-a+e^-b)) ).
+ * So a partial result of the recursion decoder.cpp:31-44 that is only fed into further box-pluses never
+ * has to leave the E domain: it is carried as (sign, E) and combined with
  *
- * The rewrite needs E(x), E(y) to be normal numbers: callers use it only while every operand of the check
- * node satisfies |v| <= DM_SHARED_LIMIT (box-plus results never exceed their smaller operand in magnitude)
- * and fall back to dm_boxplus for the whole node otherwise (e.g. two shortened bits, LLR 99999.9).
+ *     dm_e_combine(Ex, Ey) = (Ex + Ey) / (1 + Ex Ey)             one fma, one add, one IEEE division
+ *
+ * A degree-d check node then costs d exponentials (its inputs), 3(d-2) combines and d logarithms (its
+ * outputs) instead of 2 exponentials, a division and a logarithm for each of its 3(d-2) box-pluses.
+ * Same recursion order as the reference (F[j] from F[j-1] and input j, B[j] from B[j+1] and input j, output
+ * j from F[j-1] and B[j+1]); the arithmetic differs from the libm expression by a few 1e-16 absolute.
+ *
+ * E must be a normal number: the caller uses this form only while every input of the node satisfies
+ * |v| <= DM_SHARED_LIMIT (partial results never exceed their smaller operand in magnitude) and evaluates the
+ * node with dm_boxplus otherwise (e.g. two shortened bits, LLR 99999.9, on one check node).
  * ------------------------------------------------------------------------------------------------ */
 #define DM_SHARED_LIMIT 600.0
 
-DM_FN double dm_boxplus_shared(double x, double y, double ex, double ey)
+DM_FN double dm_e_combine(double ex, double ey) { return (ex + ey) / DM_FMA(ex, ey, 1.0); }
+
+/* LLR of a partial result carried as (sign bit, E): s * (-log E); an exact zero comes out as +0.0, as in
+   the reference where log(1) = +0.0 is added to a signed zero */
+DM_FN double dm_e_to_llr(uint64_t sign_bit, double e)
 {
-    double mn = __builtin_fmin(__builtin_fabs(x), __builtin_fabs(y));
-    uint64_t sgn = (dm_bits(x) ^ dm_bits(y)) & 0x8000000000000000ull;
-    double m = dm_from_bits(dm_bits(mn) | sgn);          /* s min(|x|,|y|) */
-    double sd = dm_from_bits(0x3FF0000000000000ull | sgn); /* s as +-1.0 */
-    double p = ex * ey;
-    double emx = __builtin_fmax(ex, ey), emn = __builtin_fmin(ex, ey);
-    double num = DM_FMA(emx, p, emx); /* Emax (1 + P) */
-    double den = emx + emn;
-    double l = dm_boxplus_log(num / den); /* <= 0 */
-    /* s * l, with +0.0 for l == 0 as in the reference, where log(1) = +0 is added to -0.0 */
-    return m + DM_FMA(sd, l, 0.0);
+    double mag = 0.0 - dm_boxplus_log(e);
+    double sd = dm_from_bits(0x3FF0000000000000ull | sign_bit);
+    return DM_FMA(sd, mag, 0.0);
 }
+
+#define DM_SIGN_BIT(x) (dm_bits(x) & 0x8000000000000000ull)
 
 #endif /* LDPC_AMD_DETMATH_H */

@@ -42,10 +42,10 @@ __device__ __forceinline__ void cn_update(double *m, int stride)
 #pragma unroll
     for (int j = 0; j < D; ++j)
         v[j] = m[j * stride];
-    if constexpr (!MINSUM)
+    if constexpr (!MINSUM && D > 2) // a degree-2 node only swaps its two inputs: the generic code below
     {
-        // sum-product: exponentials shared between the node's box-pluses (detmath.h, dm_boxplus_shared),
-        // valid while every operand is within DM_SHARED_LIMIT; otherwise the direct form below
+        // sum-product: the recursion is carried in E = e^-|L| (detmath.h, dm_e_combine / dm_e_to_llr) while
+        // every input is within DM_SHARED_LIMIT; otherwise the direct box-plus below
         double amax = 0.0;
 #pragma unroll
         for (int j = 0; j < D; ++j)
@@ -53,30 +53,32 @@ __device__ __forceinline__ void cn_update(double *m, int stride)
         if (amax <= DM_SHARED_LIMIT)
         {
             double ev[D], eF[D], eB[D];
+            uint64_t sv[D], sF[D], sB[D];
 #pragma unroll
             for (int j = 0; j < D; ++j)
+            {
                 ev[j] = dm_boxplus_exp(__builtin_fabs(v[j]));
-            F[0] = v[0], eF[0] = ev[0];
-            B[D - 1] = v[D - 1], eB[D - 1] = ev[D - 1];
+                sv[j] = DM_SIGN_BIT(v[j]);
+            }
+            eF[0] = ev[0], sF[0] = sv[0];
+            eB[D - 1] = ev[D - 1], sB[D - 1] = sv[D - 1];
 #pragma unroll
             for (int j = 1; j < D - 1; ++j)
             {
-                F[j] = dm_boxplus_shared(F[j - 1], v[j], eF[j - 1], ev[j]);
-                if (j < D - 2) // F[D-2] is only an output
-                    eF[j] = dm_boxplus_exp(__builtin_fabs(F[j]));
+                eF[j] = dm_e_combine(eF[j - 1], ev[j]);
+                sF[j] = sF[j - 1] ^ sv[j];
             }
 #pragma unroll
             for (int j = D - 2; j >= 1; --j)
             {
-                B[j] = dm_boxplus_shared(B[j + 1], v[j], eB[j + 1], ev[j]);
-                if (j > 1) // B[1] is only an output
-                    eB[j] = dm_boxplus_exp(__builtin_fabs(B[j]));
+                eB[j] = dm_e_combine(eB[j + 1], ev[j]);
+                sB[j] = sB[j + 1] ^ sv[j];
             }
-            m[0] = B[1];
-            m[(D - 1) * stride] = F[D - 2];
+            m[0] = dm_e_to_llr(sB[1], eB[1]);
+            m[(D - 1) * stride] = dm_e_to_llr(sF[D - 2], eF[D - 2]);
 #pragma unroll
             for (int j = 1; j < D - 1; ++j)
-                m[j * stride] = dm_boxplus_shared(F[j - 1], B[j + 1], eF[j - 1], eB[j + 1]);
+                m[j * stride] = dm_e_to_llr(sF[j - 1] ^ sB[j + 1], dm_e_combine(eF[j - 1], eB[j + 1]));
             return;
         }
     }

@@ -366,17 +366,17 @@ static void dec_free(dec_t *d)
 }
 
 /*
- * ORC_MATH_DET only: the same forward/backward recursion (decoder.cpp:31-44) with the exponentials shared
- * between the box-pluses of the node (detmath.h, dm_boxplus_shared) — the arithmetic the HIP kernel runs.
- * Returns 0 (nothing done) when an operand exceeds DM_SHARED_LIMIT; the caller then takes the direct
- * dm_boxplus path for this node, as the kernel does.  F[cw-1] and B[0], which the reference computes and
- * never reads, are not evaluated.
+ * ORC_MATH_DET only: the forward/backward recursion (decoder.cpp:31-44) carried in E = e^-|L| (detmath.h,
+ * dm_e_combine / dm_e_to_llr) — the arithmetic the HIP kernel runs.  Returns 0 (nothing done) when an input
+ * exceeds DM_SHARED_LIMIT; the caller then evaluates this node with dm_boxplus, as the kernel does.
+ * F[cw-1] and B[0], which the reference computes and never reads, are not evaluated.
  */
 static int cn_update_det_shared(dec_t *d, const int *cn, int cw)
 {
     enum { MAXD = 64 };
-    double v[MAXD], ev[MAXD], F[MAXD], eF[MAXD], B[MAXD], eB[MAXD];
-    if (cw > MAXD || cw < 2)
+    double v[MAXD], ev[MAXD], eF[MAXD], eB[MAXD];
+    uint64_t sv[MAXD], sF[MAXD], sB[MAXD];
+    if (cw > MAXD || cw < 3) /* a degree-2 node only swaps its inputs: generic path */
         return 0;
     for (int j = 0; j < cw; ++j)
     {
@@ -385,23 +385,26 @@ static int cn_update_det_shared(dec_t *d, const int *cn, int cw)
             return 0;
     }
     for (int j = 0; j < cw; ++j)
+    {
         ev[j] = dm_boxplus_exp(fabs(v[j]));
-    F[0] = v[0], eF[0] = ev[0];
-    B[cw - 1] = v[cw - 1], eB[cw - 1] = ev[cw - 1];
+        sv[j] = DM_SIGN_BIT(v[j]);
+    }
+    eF[0] = ev[0], sF[0] = sv[0];
+    eB[cw - 1] = ev[cw - 1], sB[cw - 1] = sv[cw - 1];
     for (int j = 1; j < cw - 1; ++j)
     {
-        F[j] = dm_boxplus_shared(F[j - 1], v[j], eF[j - 1], ev[j]);
-        eF[j] = dm_boxplus_exp(fabs(F[j]));
+        eF[j] = dm_e_combine(eF[j - 1], ev[j]);
+        sF[j] = sF[j - 1] ^ sv[j];
     }
     for (int j = cw - 2; j >= 1; --j)
     {
-        B[j] = dm_boxplus_shared(B[j + 1], v[j], eB[j + 1], ev[j]);
-        eB[j] = dm_boxplus_exp(fabs(B[j]));
+        eB[j] = dm_e_combine(eB[j + 1], ev[j]);
+        sB[j] = sB[j + 1] ^ sv[j];
     }
-    d->c2v[cn[0]] = B[1];
-    d->c2v[cn[cw - 1]] = F[cw - 2];
+    d->c2v[cn[0]] = dm_e_to_llr(sB[1], eB[1]);
+    d->c2v[cn[cw - 1]] = dm_e_to_llr(sF[cw - 2], eF[cw - 2]);
     for (int j = 1; j < cw - 1; ++j)
-        d->c2v[cn[j]] = dm_boxplus_shared(F[j - 1], B[j + 1], eF[j - 1], eB[j + 1]);
+        d->c2v[cn[j]] = dm_e_to_llr(sF[j - 1] ^ sB[j + 1], dm_e_combine(eF[j - 1], eB[j + 1]));
     return 1;
 }
 

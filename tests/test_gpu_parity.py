@@ -34,10 +34,10 @@ def ocode():
 
 # ------------------------------------------------------------------------------------------------
 def test_device_mt19937_64_matches_stream(dec):
-    ref = orc.mt64_stream(0, 200000)
-    got = dec.mt64(0, 0, 200000)  # crosses three 65520-word chunks: exercises the jump-ahead states
+    ref = orc.mt64_stream(0, 800000)
+    got = dec.mt64(0, 0, 800000)  # crosses three 262080-word chunks: exercises the jump-ahead states
     assert np.array_equal(ref, got)
-    for seed, first, n in [(5489, 9999, 1), (7, 65519, 3), (123456789, 131040 - 5, 700)]:
+    for seed, first, n in [(5489, 9999, 1), (7, 262079, 3), (123456789, 524160 - 5, 700)]:
         ref = orc.mt64_stream(seed, first + n)[first:]
         assert np.array_equal(ref, dec.mt64(seed, first, n)), (seed, first, n)
     # ISO C++ known answer: 10000th output of mt19937_64(5489)
@@ -45,7 +45,7 @@ def test_device_mt19937_64_matches_stream(dec):
 
 
 def test_device_mt19937_64_far_seek(dec):
-    first = 40_000_000  # ~610 chunks ahead: states come from 10 doubling rounds
+    first = 40_000_000  # ~150 chunks ahead: states come from 8 doubling rounds
     ref = orc.mt64_stream(42, first + 1000)[first:]
     assert np.array_equal(ref, dec.mt64(42, first, 1000))
 

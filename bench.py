@@ -35,6 +35,17 @@ def algorithmic_bytes_per_edge_update(early_term):
     return (32 * NNZ + 17 * NC + (NNZ if early_term else 0)) / NNZ
 
 
+def measured_traffic():
+    """HBM bytes per launch of the decode kernel from the committed PMC passes (profiles/*_traffic.json, written by
+    tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    t = json.load(open(files[-1]))
+    return t.get("hbm_bytes_per_launch"), os.path.basename(files[-1])
+
+
 def cpu_baseline(seconds_budget=20.0):
     """Reference CPU path on this box's host cores, bounded sample of the same workload."""
     cores = os.cpu_count() or 1
@@ -161,6 +172,7 @@ def main():
         bpe = algorithmic_bytes_per_edge_update(early)
         eu_rank = edge_updates / world
         achieved = eu_rank * bpe / k_s / 1e9 if k_s > 0 else None
+        traffic, traffic_src = measured_traffic() if (B == 65536 and early and args.decoding == "BP") else (None, None)
         res = {
             "metric": "decoded frames/s (n=1024 code, 50 BP iters, AWGN)",
             "value": fps,
@@ -180,8 +192,9 @@ def main():
                        "frames_per_step": B * world, "parallelism": f"frame-shard x{world}"},
             "fer": fec / frames, "ber": bec / (frames * NC), "avg_iter": it_sum / frames,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
-                         "kernel": "decode_lds_kernel", "kernel_ms_avg": sum(kernel_ms) / len(kernel_ms),
+                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_src, "kernel": "decode_kernel<BP, LDS-resident>",
+                         "algorithmic_bytes_per_launch": eu_rank / K * bpe, "kernel_ms_avg": sum(kernel_ms) / len(kernel_ms),
                          "rng_ms_avg": sum(rng_ms) / len(rng_ms), "bytes_per_edge_update": bpe,
                          "note": "messages are LDS-resident: achieved = algorithmic fp64 bytes of the reference "
                                  "dataflow / kernel time, not HBM traffic (see DESIGN.md)"},

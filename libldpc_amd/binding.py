@@ -114,7 +114,8 @@ class HipDecoder:
         self.lib.ldpc_hip_code_info(self.ctx, info)
         (self.nc, self.mc, self.nnz, self.nct, self.mct, self.kct, self.kc, self.max_degree, lds,
          self.lds_bytes) = list(info)
-        self.lds_resident = bool(lds)
+        self.lds_resident = lds == 1
+        self.residency = {0: "memory", 1: "lds", 2: "registers"}[int(lds)]
 
     def close(self):
         if getattr(self, "ctx", None):

@@ -17,12 +17,12 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libldpc.so")
 CLI = os.path.join(PKG, "ldpcsim")
 
-LIB_SOURCES = ["kernels.hip", "rng_kernels.hip", "engine.cpp", "api.cpp", "sim.cpp", "code.cpp", "plan.cpp", "mt64.cpp"]
+LIB_SOURCES = ["kernels.hip", "kernels_reg.hip", "rng_kernels.hip", "engine.cpp", "api.cpp", "sim.cpp", "code.cpp", "plan.cpp", "mt64.cpp"]
 CLI_SOURCES = ["ldpcsim_main.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every fused multiply-add is written explicitly (detmath.h); results must not
 # depend on the compiler's contraction choices.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 

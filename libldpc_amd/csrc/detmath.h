@@ -277,13 +277,14 @@ DM_FN double dm_e_combine(double ex, double ey) { return (ex + ey) / DM_FMA(ex, 
 
 /* LLR of a partial result carried as (sign bit, E): s * (-log E); an exact zero comes out as +0.0, as in
    the reference where log(1) = +0.0 is added to a signed zero */
-DM_FN double dm_e_to_llr(uint64_t sign_bit, double e)
+DM_FN double dm_e_to_llr(uint32_t sign_word, double e)
 {
     double mag = 0.0 - dm_boxplus_log(e);
-    double sd = dm_from_bits(0x3FF0000000000000ull | sign_bit);
+    double sd = dm_from_bits((uint64_t)(0x3FF00000u | (sign_word & 0x80000000u)) << 32); /* s as +-1.0 */
     return DM_FMA(sd, mag, 0.0);
 }
 
-#define DM_SIGN_BIT(x) (dm_bits(x) & 0x8000000000000000ull)
+/* sign carried as the upper word of the double (bit 31 = sign); signs combine by xor of these words */
+#define DM_SIGN_WORD(x) ((uint32_t)(dm_bits(x) >> 32))
 
 #endif /* LDPC_AMD_DETMATH_H */

@@ -1,0 +1,82 @@
+// device_channel.hpp — channel + LLR initialisation fused into the decoder launches.
+//
+// Restates channel_awgn / channel_bsc ::simulate + ::calculate_llrs (src/sim/channel.cpp:62-93, 129-162) and
+// the scatter of the C-ABI decode() (src/shared.cpp:50-55) for one frame, executed by the NT threads of the
+// frame's workgroup.  `llr` is the frame's input-LLR array in VN-rank order (LDS or device memory).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+namespace ldpc_amd
+{
+
+template <int NT>
+__device__ __forceinline__ void channel_init(const DecodeArgs &a, uint64_t frame, double *llr, int tid)
+{
+    const DevPlan &P = a.plan;
+    const int nc = P.nc, nct = P.nct;
+    const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
+    constexpr int kThreads = NT;
+    // ---- channel + LLR initialisation (channel.cpp:70-93 / 137-162 / shared.cpp:50-55) ----
+    if (a.mode == kModeLlr)
+    {
+        const double *in = a.llr_in + frame * nc;
+        for (int r = tid; r < nc; r += kThreads)
+            llr[r] = in[P.rank_col[r]];
+    }
+    else
+    {
+        for (int r = tid; r < nc; r += kThreads)
+        {
+            uint8_t k = P.rank_kind[r];
+            if (k == 1)
+                llr[r] = 0.0; // punctured = erasure
+            else if (k == 2)
+                llr[r] = a.shorten_llr;
+            else if (k == 3)
+                llr[r] = 0.0; // never written by the channel: keeps the decoder's initial zero
+        }
+        if (a.mode == kModeAwgn)
+        {
+            // normal g of the stream is element (g & 1) of accepted polar pair g >> 1:
+            // element 0 = y*mult, element 1 = x*mult (libstdc++ returns y first and saves x)
+            const uint64_t g0 = a.normal_base + frame * static_cast<uint64_t>(nct);
+            const uint64_t q_lo = g0 >> 1, q_hi = (g0 + nct - 1) >> 1;
+            for (uint64_t q = q_lo + tid; q <= q_hi; q += kThreads)
+            {
+                const uint64_t *pp = a.pairs + 2 * (q - a.pair_base);
+                PolarTrial t = polar_trial(pp[0], pp[1]);
+                double mult = __builtin_sqrt(-2 * dm_log(t.r2) / t.r2);
+                double nrm[2] = {t.y * mult, t.x * mult};
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                {
+                    uint64_t g = 2 * q + k;
+                    if (g < g0 || g >= g0 + nct)
+                        continue;
+                    int i = static_cast<int>(g - g0);
+                    double noise = nrm[k] * a.sigma + 0.0;
+                    double xs = cw ? static_cast<double>(1 - 2 * static_cast<int>(cw[P.bit_pos[i]])) : 1.0;
+                    double y = noise + xs;
+                    llr[P.tx_rank[i]] = 2 * y / a.sigma2;
+                }
+            }
+        }
+        else // kModeBsc
+        {
+            const uint64_t *raw = a.raw + frame * static_cast<uint64_t>(nct);
+            for (int i = tid; i < nct; i += kThreads)
+            {
+                int flip = canonical(raw[i]) < a.eps;
+                int xb = cw ? static_cast<int>(cw[P.bit_pos[i]]) : 0;
+                int y = xb ^ flip;
+                llr[P.tx_rank[i]] = a.delta * static_cast<double>(1 - 2 * y);
+            }
+        }
+    }
+}
+
+} // namespace ldpc_amd

@@ -237,6 +237,13 @@ Engine::Engine(const std::string &pc_file, const std::string &gen_file, int devi
     if (code_->min_cn_degree() < 2)
         throw std::runtime_error("check nodes of degree < 2 are not supported (undefined in the reference decoder)");
     plan_ = build_plan(*code_);
+    if (!plan_.lds_ok) // register-resident decoder: the smallest register tile the code fits
+        for (auto [kc, maxd] : {std::pair<int, int>{4, 6}, {8, 4}, {2, 8}})
+        {
+            reg_plan_ = build_reg_plan(*code_, plan_, kc, maxd);
+            if (reg_plan_.ok)
+                break;
+        }
 }
 
 Engine::~Engine()
@@ -313,6 +320,16 @@ void Engine::upload_plan()
     UP(rank_slot0, p.rank_slot0);
     UP(bit_pos, code_->bit_pos);
 #undef UP
+    if (reg_plan_.ok)
+    {
+        const RegPlan &r = reg_plan_;
+        dev_reg_.kc = r.kc, dev_reg_.maxd = r.maxd, dev_reg_.rounds = r.rounds, dev_reg_.mb_doubles = r.mb_doubles;
+        dev_reg_.cn_edge = static_cast<const uint32_t *>(up(r.cn_edge.data(), r.cn_edge.size() * 4));
+        dev_reg_.cn_deg = static_cast<const uint8_t *>(up(r.cn_deg.data(), r.cn_deg.size()));
+        dev_reg_.cn_cnt = static_cast<const uint8_t *>(up(r.cn_cnt.data(), r.cn_cnt.size()));
+        dev_reg_.vn_blocks = static_cast<const RegVnBlock *>(up(r.vn_blocks.data(), r.vn_blocks.size() * sizeof(RegVnBlock)));
+        dev_reg_.round_first = static_cast<const uint32_t *>(up(r.round_first.data(), r.round_first.size() * 4));
+    }
     if (code_->has_G())
     {
         std::vector<uint32_t> cp(code_->G.cptr.begin(), code_->G.cptr.end()), cr(code_->G.crow.begin(), code_->G.crow.end());
@@ -327,7 +344,7 @@ void Engine::synchronize(void *stream) { check(hipStreamSynchronize(static_cast<
 // frames per launch: bounded so that the noise-stream buffers and the memory-resident workspace stay modest
 uint64_t Engine::max_sub_batch() const
 {
-    if (plan_.lds_ok)
+    if (plan_.lds_ok || reg_plan_.ok)
         return 1u << 17;
     const uint64_t per_frame = 8ull * plan_.nnz + 8ull * plan_.nc + plan_.nnz;
     return std::max<uint64_t>(1, std::min<uint64_t>(1u << 17, (8ull << 30) / per_frame));
@@ -361,6 +378,12 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         if (const char *e = std::getenv("LDPC_AMD_LDS_PAD")) // occupancy experiments: extra dynamic LDS per frame
             a.plan.lds_bytes += static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) & ~15u;
         check(launch_decode_lds(a, p.min_sum, plan_.max_cn_degree, s), "decode (LDS-resident)");
+    }
+    else if (reg_plan_.ok && !std::getenv("LDPC_AMD_NO_REG"))
+    {
+        a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
+        a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nc));
+        check(launch_decode_reg(a, dev_reg_, p.min_sum, s), "decode (register-resident)");
     }
     else if (plan_.hbm_ok)
     {

@@ -91,6 +91,7 @@ class Engine
 
     const LdpcCode &code() const { return *code_; }
     const Plan &plan() const { return plan_; }
+    const RegPlan &reg_plan() const { return reg_plan_; }
     int device() const { return device_; }
     bool bec_deg1_compat = false;
 
@@ -130,7 +131,9 @@ class Engine
 
     std::unique_ptr<LdpcCode> code_;
     Plan plan_;
+    RegPlan reg_plan_;
     DevPlan dev_{};
+    DevRegPlan dev_reg_{};
     int device_ = 0;
     std::vector<void *> owned_;
 

@@ -18,6 +18,8 @@
 //   bit-error count        src/sim/ldpcsim.cpp:184-188
 #include <hip/hip_runtime.h>
 
+#include "device_channel.hpp"
+#include "device_cn.hpp"
 #include "device_math.hpp"
 #include "kernels.hpp"
 
@@ -30,71 +32,18 @@ namespace
 constexpr int kThreads = kDecodeWaves * kWaveSize;
 constexpr uint8_t kErasure = 'E'; // functions.h:105
 
-// ---------------------------------------------------------------------------------------------
-// check-node update of one node held by one lane: forward/backward recursion, decoder.cpp:31-44.
-// m[j*stride] = v2c of the node's j-th edge (row file order); replaced by c2v.  The reference also
-// evaluates F[cw-1] and B[0], which nothing reads; they are skipped.
-// ---------------------------------------------------------------------------------------------
+// check-node update on the frame's message array: slot(j) = m[j*stride] (decoder.cpp:25-45, device_cn.hpp)
 template <int D, bool MINSUM>
 __device__ __forceinline__ void cn_update(double *m, int stride)
 {
-    double v[D], F[D], B[D];
+    double v[D];
 #pragma unroll
     for (int j = 0; j < D; ++j)
         v[j] = m[j * stride];
-    if constexpr (!MINSUM && D > 2) // a degree-2 node only swaps its two inputs: the generic code below
-    {
-        // sum-product: the recursion is carried in E = e^-|L| (detmath.h, dm_e_combine / dm_e_to_llr) while
-        // every input is within DM_SHARED_LIMIT; otherwise the direct box-plus below
-        double amax = 0.0;
+    cn_core<D, MINSUM>(v);
 #pragma unroll
-        for (int j = 0; j < D; ++j)
-            amax = __builtin_fmax(amax, __builtin_fabs(v[j]));
-        if (amax <= DM_SHARED_LIMIT)
-        {
-            double ev[D], eF[D], eB[D];
-            uint64_t sv[D], sF[D], sB[D];
-#pragma unroll
-            for (int j = 0; j < D; ++j)
-            {
-                ev[j] = dm_boxplus_exp(__builtin_fabs(v[j]));
-                sv[j] = DM_SIGN_BIT(v[j]);
-            }
-            eF[0] = ev[0], sF[0] = sv[0];
-            eB[D - 1] = ev[D - 1], sB[D - 1] = sv[D - 1];
-#pragma unroll
-            for (int j = 1; j < D - 1; ++j)
-            {
-                eF[j] = dm_e_combine(eF[j - 1], ev[j]);
-                sF[j] = sF[j - 1] ^ sv[j];
-            }
-#pragma unroll
-            for (int j = D - 2; j >= 1; --j)
-            {
-                eB[j] = dm_e_combine(eB[j + 1], ev[j]);
-                sB[j] = sB[j + 1] ^ sv[j];
-            }
-            m[0] = dm_e_to_llr(sB[1], eB[1]);
-            m[(D - 1) * stride] = dm_e_to_llr(sF[D - 2], eF[D - 2]);
-#pragma unroll
-            for (int j = 1; j < D - 1; ++j)
-                m[j * stride] = dm_e_to_llr(sF[j - 1] ^ sB[j + 1], dm_e_combine(eF[j - 1], eB[j + 1]));
-            return;
-        }
-    }
-    F[0] = v[0];
-    B[D - 1] = v[D - 1];
-#pragma unroll
-    for (int j = 1; j < D - 1; ++j)
-        F[j] = boxplus<MINSUM>(F[j - 1], v[j]);
-#pragma unroll
-    for (int j = D - 2; j >= 1; --j)
-        B[j] = boxplus<MINSUM>(B[j + 1], v[j]);
-    m[0] = B[1];
-    m[(D - 1) * stride] = F[D - 2];
-#pragma unroll
-    for (int j = 1; j < D - 1; ++j)
-        m[j * stride] = boxplus<MINSUM>(F[j - 1], B[j + 1]);
+    for (int j = 0; j < D; ++j)
+        m[j * stride] = v[j];
 }
 
 template <bool MINSUM, int MAXD>
@@ -163,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
     extern __shared__ double lds[];
     __shared__ int misc[4];
     const DevPlan &P = a.plan;
-    const int nnz = P.nnz, nc = P.nc, nct = P.nct;
+    const int nnz = P.nnz, nc = P.nc;
     const uint64_t frame = blockIdx.x;
     double *msg, *llr;
     uint8_t *hb;
@@ -196,63 +145,8 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
     if (tid == 0)
         misc[0] = 0;
 
-    // ---- channel + LLR initialisation (channel.cpp:70-93 / 137-162 / shared.cpp:50-55) ----
-    if (a.mode == kModeLlr)
-    {
-        const double *in = a.llr_in + frame * nc;
-        for (int r = tid; r < nc; r += kThreads)
-            llr[r] = in[P.rank_col[r]];
-    }
-    else
-    {
-        for (int r = tid; r < nc; r += kThreads)
-        {
-            uint8_t k = P.rank_kind[r];
-            if (k == 1)
-                llr[r] = 0.0; // punctured = erasure
-            else if (k == 2)
-                llr[r] = a.shorten_llr;
-            else if (k == 3)
-                llr[r] = 0.0; // never written by the channel: keeps the decoder's initial zero
-        }
-        if (a.mode == kModeAwgn)
-        {
-            // normal g of the stream is element (g & 1) of accepted polar pair g >> 1:
-            // element 0 = y*mult, element 1 = x*mult (libstdc++ returns y first and saves x)
-            const uint64_t g0 = a.normal_base + frame * static_cast<uint64_t>(nct);
-            const uint64_t q_lo = g0 >> 1, q_hi = (g0 + nct - 1) >> 1;
-            for (uint64_t q = q_lo + tid; q <= q_hi; q += kThreads)
-            {
-                const uint64_t *pp = a.pairs + 2 * (q - a.pair_base);
-                PolarTrial t = polar_trial(pp[0], pp[1]);
-                double mult = __builtin_sqrt(-2 * dm_log(t.r2) / t.r2);
-                double nrm[2] = {t.y * mult, t.x * mult};
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                {
-                    uint64_t g = 2 * q + k;
-                    if (g < g0 || g >= g0 + nct)
-                        continue;
-                    int i = static_cast<int>(g - g0);
-                    double noise = nrm[k] * a.sigma + 0.0;
-                    double xs = cw ? static_cast<double>(1 - 2 * static_cast<int>(cw[P.bit_pos[i]])) : 1.0;
-                    double y = noise + xs;
-                    llr[P.tx_rank[i]] = 2 * y / a.sigma2;
-                }
-            }
-        }
-        else // kModeBsc
-        {
-            const uint64_t *raw = a.raw + frame * static_cast<uint64_t>(nct);
-            for (int i = tid; i < nct; i += kThreads)
-            {
-                int flip = canonical(raw[i]) < a.eps;
-                int xb = cw ? static_cast<int>(cw[P.bit_pos[i]]) : 0;
-                int y = xb ^ flip;
-                llr[P.tx_rank[i]] = a.delta * static_cast<double>(1 - 2 * y);
-            }
-        }
-    }
+    // ---- channel + LLR initialisation (device_channel.hpp) ----
+    channel_init<kThreads>(a, frame, llr, tid);
     __syncthreads();
 
     if (a.llr_in_dump)

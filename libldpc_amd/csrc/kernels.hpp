@@ -69,6 +69,18 @@ struct DecodeArgs
     uint8_t *ws_hb;  // [n_frames][nnz]
 };
 
+// device copy of RegPlan (register-resident decoder, kernels_reg.hip)
+struct DevRegPlan
+{
+    int kc, maxd, rounds;
+    uint32_t mb_doubles;
+    const uint32_t *cn_edge;
+    const uint8_t *cn_deg;
+    const uint8_t *cn_cnt;
+    const RegVnBlock *vn_blocks;
+    const uint32_t *round_first;
+};
+
 // BEC (u8 erasure alphabet, decoder.cpp:91-192 + channel.cpp:199-229)
 struct BecArgs
 {
@@ -94,6 +106,8 @@ int launch_decode_lds(const DecodeArgs &a, bool min_sum, int max_cn_degree, void
 // memory-resident variant for codes whose messages do not fit LDS (a.ws_* must be set); occupancy_lds
 // bytes of dynamic LDS are requested only to bound the number of resident frames per CU
 int launch_decode_mem(const DecodeArgs &a, bool min_sum, int max_cn_degree, uint32_t occupancy_lds, void *stream);
+// register-resident decoder: a.ws_llr [n][nc] doubles and a.ws_hb [n][nc] bytes must be set
+int launch_decode_reg(const DecodeArgs &a, const DevRegPlan &r, bool min_sum, void *stream);
 int launch_bec(const BecArgs &a, void *stream);
 
 // ---- mt19937_64 on the device ----

@@ -1,0 +1,300 @@
+// kernels_reg.hip — register-resident BP / min-sum decoder for codes whose messages do not fit LDS four
+// frames at a time (BASELINE config 4: (3,6)-regular n=8192, 196 KB of fp64 messages per frame).
+//
+// One 1024-thread workgroup decodes one frame on one CU.  The frame's messages live in the register file:
+// thread (wave, lane) owns the check nodes of CN blocks k*16 + wave (k < KC) and holds their KC x MAXD messages
+// in m[k][j] for the whole decode, so the check-node pass — 80 % of the arithmetic — touches no memory at all.
+// The variable-node side is reached through an LDS mailbox laid out VN-block-major: CN threads scatter c2v,
+// VN threads read their column contiguously ([position][lane]: conflict-free), form the APP in column file
+// order, write v2c and the hard decision back in place, CN threads gather.  A code whose edges exceed the
+// mailbox (160 KB = 18 176 entries of 8+1 bytes) is exchanged in rounds of VN blocks.  Input LLRs and per-VN
+// hard decisions sit in device memory (read / written once per VN per iteration, coalesced).
+//
+// Same arithmetic, same order as the LDS-resident kernel (kernels.hip) and as the reference:
+//   decode loop src/decoding/decoder.cpp:11-78, CN recursion :31-44 (device_cn.hpp), VN sum :50-56 in column
+//   file order, syndrome src/decoding/decoder.h:47-64, channels src/sim/channel.cpp (device_channel.hpp).
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+#include "device_channel.hpp"
+#include "device_cn.hpp"
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+namespace ldpc_amd
+{
+
+namespace
+{
+
+constexpr int NT = kRegThreads;
+
+template <bool MINSUM, int MAXD>
+__device__ __forceinline__ void cn_regs(double (&m)[MAXD], int degree)
+{
+    // wave-uniform degree: one fully unrolled recursion per width
+#define LDPC_CASE(D)                         \
+    case D:                                  \
+    {                                        \
+        double v[D];                         \
+        _Pragma("unroll") for (int j = 0; j < D; ++j) v[j] = m[j]; \
+        cn_core<D, MINSUM>(v);               \
+        _Pragma("unroll") for (int j = 0; j < D; ++j) m[j] = v[j]; \
+        break;                               \
+    }
+    switch (degree)
+    {
+        LDPC_CASE(2)
+        LDPC_CASE(3)
+    default:
+        if constexpr (MAXD >= 4)
+            switch (degree)
+            {
+                LDPC_CASE(4)
+            default:
+                if constexpr (MAXD >= 6)
+                    switch (degree)
+                    {
+                        LDPC_CASE(5)
+                        LDPC_CASE(6)
+                    default:
+                        if constexpr (MAXD >= 8)
+                            switch (degree)
+                            {
+                                LDPC_CASE(7)
+                                LDPC_CASE(8)
+                            default: break;
+                            }
+                        break;
+                    }
+                break;
+            }
+        break;
+    }
+#undef LDPC_CASE
+}
+
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <bool MINSUM, bool WANT_LLR, int KC, int MAXD>
+__global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, const DevRegPlan R)
+{
+    extern __shared__ double mb[]; // mailbox: mb_doubles doubles, then mb_doubles hard-bit bytes
+    __shared__ int misc[4];
+    uint8_t *hbm = reinterpret_cast<uint8_t *>(mb + R.mb_doubles);
+    const DevPlan &P = a.plan;
+    const int nc = P.nc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t frame = blockIdx.x;
+    double *llr = a.ws_llr + frame * nc;
+    uint8_t *hard = a.ws_hb + frame * nc;
+    const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
+
+    if (tid == 0)
+        misc[0] = 0;
+    channel_init<NT>(a, frame, llr, tid);
+    __syncthreads();
+    if (a.llr_in_dump)
+    {
+        double *o = a.llr_in_dump + frame * nc;
+        for (int r = tid; r < nc; r += NT)
+            o[P.rank_col[r]] = llr[r];
+    }
+
+    double m[KC][MAXD];
+    int deg[KC];
+    bool have[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+    {
+        deg[k] = R.cn_deg[k * kRegWaves + wave];
+        have[k] = lane < R.cn_cnt[k * kRegWaves + wave];
+#pragma unroll
+        for (int j = 0; j < MAXD; ++j)
+            m[k][j] = 0.0;
+    }
+    const uint32_t *my_edge = R.cn_edge + tid;
+
+    // ---- v2c initialisation (decoder.cpp:16-19): every edge starts with its VN's input LLR ----
+    for (int r = 0; r < R.rounds; ++r)
+    {
+        for (uint32_t b = R.round_first[r] + wave; b < R.round_first[r + 1]; b += kRegWaves)
+        {
+            const RegVnBlock vb = R.vn_blocks[b];
+            if (lane < vb.count)
+            {
+                const double L = llr[vb.first + lane];
+                for (int p = 0; p < vb.degree; ++p)
+                    mb[vb.mb_off + p * vb.count + lane] = L;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+#pragma unroll
+            for (int j = 0; j < MAXD; ++j)
+            {
+                const uint32_t e = my_edge[(k * MAXD + j) * NT];
+                if (e != kRegNoEdge && (e >> 28) == static_cast<uint32_t>(r))
+                    m[k][j] = mb[e & 0x0FFFFFFFu];
+            }
+        __syncthreads();
+    }
+
+    double *out_llr = WANT_LLR ? a.llr_out + frame * nc : nullptr;
+    uint32_t I = 0;
+    while (I < a.iterations)
+    {
+        // ---- CN pass (decoder.cpp:25-45), entirely in registers ----
+        // (a fold expression, not a loop: every m[k] must be a compile-time register row)
+        [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+            ((have[Ks] ? cn_regs<MINSUM, MAXD>(m[Ks], deg[Ks]) : void()), ...);
+        }(std::make_integer_sequence<int, KC>{});
+
+        int par[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            par[k] = 0;
+        for (int r = 0; r < R.rounds; ++r)
+        {
+            // c2v -> mailbox
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+#pragma unroll
+                for (int j = 0; j < MAXD; ++j)
+                {
+                    const uint32_t e = my_edge[(k * MAXD + j) * NT];
+                    if (e != kRegNoEdge && (e >> 28) == static_cast<uint32_t>(r))
+                        mb[e & 0x0FFFFFFFu] = m[k][j];
+                }
+            __syncthreads();
+            // ---- VN pass, APP and hard decision (decoder.cpp:48-64) on this round's VN blocks ----
+            for (uint32_t b = R.round_first[r] + wave; b < R.round_first[r + 1]; b += kRegWaves)
+            {
+                const RegVnBlock vb = R.vn_blocks[b];
+                if (lane < vb.count)
+                {
+                    const int rank = vb.first + lane;
+                    double *col = mb + vb.mb_off + lane;
+                    uint8_t *hcol = hbm + vb.mb_off + lane;
+                    double out = llr[rank];
+                    for (int p = 0; p < vb.degree; ++p) // sequential sum in column file order
+                        out += col[p * vb.count];
+                    const uint8_t bit = out <= 0;
+                    for (int p = 0; p < vb.degree; ++p)
+                    {
+                        col[p * vb.count] = out - col[p * vb.count];
+                        hcol[p * vb.count] = bit;
+                    }
+                    hard[rank] = bit;
+                    if constexpr (WANT_LLR)
+                        out_llr[P.rank_col[rank]] = out;
+                }
+            }
+            __syncthreads();
+            // v2c (and the hard decision of the edge's VN) <- mailbox
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+#pragma unroll
+                for (int j = 0; j < MAXD; ++j)
+                {
+                    const uint32_t e = my_edge[(k * MAXD + j) * NT];
+                    if (e != kRegNoEdge && (e >> 28) == static_cast<uint32_t>(r))
+                    {
+                        m[k][j] = mb[e & 0x0FFFFFFFu];
+                        par[k] ^= hbm[e & 0x0FFFFFFFu];
+                    }
+                }
+            __syncthreads();
+        }
+        // ---- syndrome early termination (decoder.cpp:66-72, decoder.h:47-64) ----
+        if (a.early_term)
+        {
+            int bad = 0;
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                bad |= have[k] ? par[k] : 0;
+            if (!__syncthreads_or(bad))
+                break;
+        }
+        ++I;
+    }
+    __syncthreads();
+
+    // ---- outputs ----
+    if (tid == 0 && a.iters)
+        a.iters[frame] = I;
+    const bool ran = a.iterations > 0;
+    if (a.hard)
+    {
+        uint8_t *h = a.hard + frame * nc;
+        for (int r = tid; r < nc; r += NT)
+            h[P.rank_col[r]] = ran ? hard[r] : 0;
+    }
+    if constexpr (WANT_LLR)
+    {
+        if (!ran)
+            for (int r = tid; r < nc; r += NT)
+                out_llr[P.rank_col[r]] = 0.0;
+    }
+    if (a.bit_errors)
+    {
+        int err = 0;
+        for (int i = tid; i < P.n_bitpos; i += NT)
+        {
+            int est = ran ? hard[P.tx_rank[i]] : 0;
+            int tx = cw ? static_cast<int>(cw[P.bit_pos[i]]) : 0;
+            err += est != tx;
+        }
+        err = wave_sum_i(err);
+        if (lane == 0 && err)
+            atomicAdd(&misc[0], err);
+        __syncthreads();
+        if (tid == 0)
+            a.bit_errors[frame] = static_cast<uint32_t>(misc[0]);
+    }
+}
+
+template <int KC, int MAXD>
+int launch_reg(const DecodeArgs &a, const DevRegPlan &r, bool min_sum, void *stream)
+{
+    const bool want_llr = a.llr_out != nullptr;
+    void (*k)(const DecodeArgs, const DevRegPlan) = nullptr;
+    if (min_sum)
+        k = want_llr ? decode_reg_kernel<true, true, KC, MAXD> : decode_reg_kernel<true, false, KC, MAXD>;
+    else
+        k = want_llr ? decode_reg_kernel<false, true, KC, MAXD> : decode_reg_kernel<false, false, KC, MAXD>;
+    const uint32_t lds = r.mb_doubles * 9u;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(a.n_frames)), dim3(NT), lds, static_cast<hipStream_t>(stream), a, r);
+    return hipGetLastError();
+}
+
+} // namespace
+
+int launch_decode_reg(const DecodeArgs &a, const DevRegPlan &r, bool min_sum, void *stream)
+{
+    if (a.n_frames == 0)
+        return hipSuccess;
+    if (!a.ws_llr || !a.ws_hb)
+        return hipErrorInvalidValue;
+    if (r.kc == 4 && r.maxd == 6)
+        return launch_reg<4, 6>(a, r, min_sum, stream);
+    if (r.kc == 8 && r.maxd == 4)
+        return launch_reg<8, 4>(a, r, min_sum, stream);
+    if (r.kc == 2 && r.maxd == 8)
+        return launch_reg<2, 8>(a, r, min_sum, stream);
+    return hipErrorInvalidValue;
+}
+
+} // namespace ldpc_amd

@@ -131,4 +131,76 @@ Plan build_plan(const LdpcCode &code)
     return p;
 }
 
+RegPlan build_reg_plan(const LdpcCode &code, const Plan &plan, int kc, int maxd)
+{
+    RegPlan r;
+    r.kc = kc, r.maxd = maxd;
+    const SparseGF2 &H = code.H;
+    const int n_cb = static_cast<int>(plan.cn_blocks.size());
+    if (code.min_cn_degree() < 2 || plan.max_cn_degree > maxd || n_cb > kc * kRegWaves || plan.nnz >= (1 << 28))
+        return r;
+    // mailbox: as many (double + hard-bit byte) entries as one CU's LDS holds
+    const uint32_t cap = ((160 * 1024 - 256) / 9) & ~63u;
+    // VN blocks (those of the LDS plan: sorted by degree, <= 64 equal-degree VNs) dealt to rounds in order
+    std::vector<uint32_t> block_round(plan.vn_blocks.size()), block_off(plan.vn_blocks.size());
+    uint32_t fill = 0, round = 0, peak = 0;
+    r.round_first.push_back(0);
+    for (size_t b = 0; b < plan.vn_blocks.size(); ++b)
+    {
+        const VnBlock &vb = plan.vn_blocks[b];
+        const uint32_t need = static_cast<uint32_t>(vb.degree) * vb.count;
+        if (need > cap)
+            return r; // a single block of very high degree: not for this kernel
+        if (fill + need > cap)
+        {
+            ++round;
+            fill = 0;
+            r.round_first.push_back(static_cast<uint32_t>(b));
+        }
+        block_round[b] = round;
+        block_off[b] = fill;
+        fill += need;
+        peak = std::max(peak, fill);
+        r.vn_blocks.push_back(RegVnBlock{vb.first, block_off[b], vb.count, vb.degree});
+    }
+    r.round_first.push_back(static_cast<uint32_t>(plan.vn_blocks.size()));
+    r.rounds = static_cast<int>(round) + 1;
+    if (r.rounds > 15)
+        return r;
+    r.mb_doubles = (peak + 63) & ~63u;
+
+    // mailbox address of every edge: (VN block, position in the column, lane)
+    std::vector<uint32_t> edge_mb(plan.nnz);
+    for (size_t b = 0; b < plan.vn_blocks.size(); ++b)
+    {
+        const VnBlock &vb = plan.vn_blocks[b];
+        for (int l = 0; l < vb.count; ++l)
+        {
+            const int col = static_cast<int>(plan.rank_col[vb.first + l]);
+            for (int p = 0; p < vb.degree; ++p)
+                edge_mb[H.cedge[H.cptr[col] + p]] = (block_round[b] << 28) | (block_off[b] + p * vb.count + l);
+        }
+    }
+    r.cn_edge.assign(static_cast<size_t>(kc) * maxd * kRegThreads, kRegNoEdge);
+    r.cn_deg.assign(static_cast<size_t>(kc) * kRegWaves, 0);
+    r.cn_cnt.assign(static_cast<size_t>(kc) * kRegWaves, 0);
+    int rank = 0; // CN rank in the LDS plan's order (cn_rank_row), block by block
+    for (int bi = 0; bi < n_cb; ++bi)
+    {
+        const CnBlock &cb = plan.cn_blocks[bi];
+        const int k = bi / kRegWaves, wave = bi % kRegWaves;
+        r.cn_deg[k * kRegWaves + wave] = static_cast<uint8_t>(cb.degree);
+        r.cn_cnt[k * kRegWaves + wave] = static_cast<uint8_t>(cb.count);
+        for (int l = 0; l < cb.count; ++l, ++rank)
+        {
+            const int row = static_cast<int>(plan.cn_rank_row[rank]);
+            const int tid = wave * kWaveSize + l;
+            for (int j = 0; j < cb.degree; ++j)
+                r.cn_edge[(static_cast<size_t>(k) * maxd + j) * kRegThreads + tid] = edge_mb[H.redge[H.rptr[row] + j]];
+        }
+    }
+    r.ok = true;
+    return r;
+}
+
 } // namespace ldpc_amd

@@ -375,7 +375,7 @@ static int cn_update_det_shared(dec_t *d, const int *cn, int cw)
 {
     enum { MAXD = 64 };
     double v[MAXD], ev[MAXD], eF[MAXD], eB[MAXD];
-    uint64_t sv[MAXD], sF[MAXD], sB[MAXD];
+    uint32_t sv[MAXD], sF[MAXD], sB[MAXD];
     if (cw > MAXD || cw < 3) /* a degree-2 node only swaps its inputs: generic path */
         return 0;
     for (int j = 0; j < cw; ++j)
@@ -387,7 +387,7 @@ static int cn_update_det_shared(dec_t *d, const int *cn, int cw)
     for (int j = 0; j < cw; ++j)
     {
         ev[j] = dm_boxplus_exp(fabs(v[j]));
-        sv[j] = DM_SIGN_BIT(v[j]);
+        sv[j] = DM_SIGN_WORD(v[j]);
     }
     eF[0] = ev[0], sF[0] = sv[0];
     eB[cw - 1] = ev[cw - 1], sB[cw - 1] = sv[cw - 1];

@@ -72,7 +72,7 @@ struct DecodeArgs
 // device copy of RegPlan (register-resident decoder, kernels_reg.hip)
 struct DevRegPlan
 {
-    int kc, maxd, rounds;
+    int nt, kc, maxd, rounds;
     uint32_t mb_doubles;
     const uint32_t *cn_edge;
     const uint8_t *cn_deg;

@@ -1,8 +1,9 @@
 // kernels_reg.hip — register-resident BP / min-sum decoder for codes whose messages do not fit LDS four
 // frames at a time (BASELINE config 4: (3,6)-regular n=8192, 196 KB of fp64 messages per frame).
 //
-// One 1024-thread workgroup decodes one frame on one CU.  The frame's messages live in the register file:
-// thread (wave, lane) owns the check nodes of CN blocks k*16 + wave (k < KC) and holds their KC x MAXD messages
+// One workgroup of NT threads decodes one frame (NT = 512: two frames per CU, so that one frame's LDS
+// exchange overlaps the other's arithmetic; NT = 1024: one).  The frame's messages live in the register file:
+// thread (wave, lane) owns the check nodes of CN blocks k*(NT/64) + wave (k < KC) and holds their KC x MAXD messages
 // in m[k][j] for the whole decode, so the check-node pass — 80 % of the arithmetic — touches no memory at all.
 // The variable-node side is reached through an LDS mailbox laid out VN-block-major: CN threads scatter c2v,
 // VN threads read their column contiguously ([position][lane]: conflict-free), form the APP in column file
@@ -27,8 +28,6 @@ namespace ldpc_amd
 
 namespace
 {
-
-constexpr int NT = kRegThreads;
 
 template <bool MINSUM, int MAXD>
 __device__ __forceinline__ void cn_regs(double (&m)[MAXD], int degree)
@@ -83,9 +82,10 @@ __device__ __forceinline__ int wave_sum_i(int v)
     return v;
 }
 
-template <bool MINSUM, bool WANT_LLR, int KC, int MAXD>
+template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD>
 __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, const DevRegPlan R)
 {
+    constexpr int kRegWaves = NT / 64;
     extern __shared__ double mb[]; // mailbox: mb_doubles doubles, then mb_doubles hard-bit bytes
     __shared__ int misc[4];
     uint8_t *hbm = reinterpret_cast<uint8_t *>(mb + R.mb_doubles);
@@ -262,15 +262,15 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
     }
 }
 
-template <int KC, int MAXD>
+template <int NT, int KC, int MAXD>
 int launch_reg(const DecodeArgs &a, const DevRegPlan &r, bool min_sum, void *stream)
 {
     const bool want_llr = a.llr_out != nullptr;
     void (*k)(const DecodeArgs, const DevRegPlan) = nullptr;
     if (min_sum)
-        k = want_llr ? decode_reg_kernel<true, true, KC, MAXD> : decode_reg_kernel<true, false, KC, MAXD>;
+        k = want_llr ? decode_reg_kernel<true, true, NT, KC, MAXD> : decode_reg_kernel<true, false, NT, KC, MAXD>;
     else
-        k = want_llr ? decode_reg_kernel<false, true, KC, MAXD> : decode_reg_kernel<false, false, KC, MAXD>;
+        k = want_llr ? decode_reg_kernel<false, true, NT, KC, MAXD> : decode_reg_kernel<false, false, NT, KC, MAXD>;
     const uint32_t lds = r.mb_doubles * 9u;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
@@ -288,12 +288,16 @@ int launch_decode_reg(const DecodeArgs &a, const DevRegPlan &r, bool min_sum, vo
         return hipSuccess;
     if (!a.ws_llr || !a.ws_hb)
         return hipErrorInvalidValue;
-    if (r.kc == 4 && r.maxd == 6)
-        return launch_reg<4, 6>(a, r, min_sum, stream);
-    if (r.kc == 8 && r.maxd == 4)
-        return launch_reg<8, 4>(a, r, min_sum, stream);
-    if (r.kc == 2 && r.maxd == 8)
-        return launch_reg<2, 8>(a, r, min_sum, stream);
+#define LDPC_TILE(N, K, D)                      \
+    if (r.nt == N && r.kc == K && r.maxd == D)  \
+        return launch_reg<N, K, D>(a, r, min_sum, stream);
+    LDPC_TILE(512, 8, 6)
+    LDPC_TILE(512, 16, 4)
+    LDPC_TILE(512, 4, 8)
+    LDPC_TILE(1024, 4, 6)
+    LDPC_TILE(1024, 8, 4)
+    LDPC_TILE(1024, 2, 8)
+#undef LDPC_TILE
     return hipErrorInvalidValue;
 }
 

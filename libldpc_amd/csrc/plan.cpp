@@ -131,16 +131,17 @@ Plan build_plan(const LdpcCode &code)
     return p;
 }
 
-RegPlan build_reg_plan(const LdpcCode &code, const Plan &plan, int kc, int maxd)
+RegPlan build_reg_plan(const LdpcCode &code, const Plan &plan, int nt, int kc, int maxd, uint32_t lds_budget)
 {
     RegPlan r;
-    r.kc = kc, r.maxd = maxd;
+    r.nt = nt, r.kc = kc, r.maxd = maxd;
+    const int kRegWaves = nt / kWaveSize, kRegThreads = nt;
     const SparseGF2 &H = code.H;
     const int n_cb = static_cast<int>(plan.cn_blocks.size());
     if (code.min_cn_degree() < 2 || plan.max_cn_degree > maxd || n_cb > kc * kRegWaves || plan.nnz >= (1 << 28))
         return r;
     // mailbox: as many (double + hard-bit byte) entries as one CU's LDS holds
-    const uint32_t cap = ((160 * 1024 - 256) / 9) & ~63u;
+    const uint32_t cap = ((lds_budget - 256) / 9) & ~63u;
     // VN blocks (those of the LDS plan: sorted by degree, <= 64 equal-degree VNs) dealt to rounds in order
     std::vector<uint32_t> block_round(plan.vn_blocks.size()), block_off(plan.vn_blocks.size());
     uint32_t fill = 0, round = 0, peak = 0;

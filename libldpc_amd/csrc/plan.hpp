@@ -71,12 +71,10 @@ struct Plan
 };
 
 // ---- register-resident decoder (codes too large for 4 frames of LDS per CU, e.g. n=8192) ----------------
-// One 1024-thread workgroup = one frame on one CU.  Thread (wave, lane) owns the check nodes of the CN blocks
-// k*16 + wave, k < kc, and keeps their messages in registers m[k][j].  The variable-node side is reached through
+// One workgroup of nt threads = one frame.  Thread (wave, lane) owns the check nodes of the CN blocks
+// k*(nt/64) + wave, k < kc, and keeps their messages in registers m[k][j].  The variable-node side is reached through
 // an LDS mailbox laid out VN-block-major ([position][lane] inside a block of <= 64 equal-degree VNs); a code
 // whose edges do not fit the mailbox at once is exchanged in `rounds` groups of VN blocks.
-constexpr int kRegThreads = 1024;
-constexpr int kRegWaves = kRegThreads / kWaveSize;
 constexpr uint32_t kRegNoEdge = 0xFFFFFFFFu;
 
 struct RegVnBlock
@@ -90,18 +88,20 @@ struct RegVnBlock
 struct RegPlan
 {
     bool ok = false;
+    int nt = 0;                     // threads per workgroup (1024: one frame per CU, 512: two)
     int kc = 0, maxd = 0;           // CN blocks per wave, register columns per CN
     int rounds = 0;
     uint32_t mb_doubles = 0;        // mailbox capacity in doubles (LDS = 9 bytes per entry)
-    std::vector<uint32_t> cn_edge;  // [(k*maxd + j)*1024 + tid] = (round << 28) | mailbox offset, kRegNoEdge = none
-    std::vector<uint8_t> cn_deg;    // [k*16 + wave] degree of that CN block (0 = none)
-    std::vector<uint8_t> cn_cnt;    // [k*16 + wave] check nodes in the block
+    std::vector<uint32_t> cn_edge;  // [(k*maxd + j)*nt + tid] = (round << 28) | mailbox offset, kRegNoEdge = none
+    std::vector<uint8_t> cn_deg;    // [k*(nt/64) + wave] degree of that CN block (0 = none)
+    std::vector<uint8_t> cn_cnt;    // [k*(nt/64) + wave] check nodes in the block
     std::vector<RegVnBlock> vn_blocks;      // in round order
     std::vector<uint32_t> round_first;      // [rounds+1] first VN block of each round
 };
 
 Plan build_plan(const LdpcCode &code);
-// `kc` x `maxd` = the register tile of the kernel instantiation to plan for
-RegPlan build_reg_plan(const LdpcCode &code, const Plan &plan, int kc, int maxd);
+// `nt` threads, `kc` x `maxd` register tile = the kernel instantiation to plan for; lds_budget = bytes of LDS
+// one workgroup may use for its mailbox
+RegPlan build_reg_plan(const LdpcCode &code, const Plan &plan, int nt, int kc, int maxd, uint32_t lds_budget);
 
 } // namespace ldpc_amd

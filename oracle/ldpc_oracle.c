@@ -557,7 +557,13 @@ static int becdec_decode(becdec_t *d, const uint8_t *x /* true codeword, gf2 val
             else
             {
                 uint8_t *F = d->F, *B = d->B;
-                if (vw == 1)
+                if (vw == 0)
+                {
+                    /* isolated erased VN: the reference indexes an empty neighbour list (undefined);
+                       defined here and in the kernel as "stays erased" */
+                    d->llr_out[i] = ORC_ERASURE;
+                }
+                else if (vw == 1)
                 {
                     /* The reference reads mExMsgF[-1] here (decoder.cpp:155-156).
                        deg1_compat reproduces what that read returns with glibc malloc (0);

@@ -1,0 +1,93 @@
+"""GPU vs. same-math oracle on randomly generated irregular codes: every decoder residency (LDS, registers,
+memory), every CN-width instantiation, degree-2 check nodes, isolated and degree-1 variable nodes, puncturing
+and shortening.  Everything is compared bit for bit (ORC_MATH_DET oracle)."""
+import zlib
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+OUT = ("iters", "bit_errors", "hard", "llr_out", "llr_in", "codeword")
+
+
+def make_code(path, nc, mc, cn_degs, rng, puncture=(), shorten=(), skip_cols=()):
+    """Random bipartite graph: check i gets cn_degs[i] distinct columns (never one in skip_cols)."""
+    cols_ok = np.array([c for c in range(nc) if c not in set(skip_cols)])
+    lines = []
+    if puncture:
+        lines.append(f"puncture [{len(puncture)}]: " + " ".join(map(str, puncture)))
+    if shorten:
+        lines.append(f"shorten [{len(shorten)}]: " + " ".join(map(str, shorten)))
+    used = np.zeros(nc, bool)
+    for i in range(mc):
+        cs = rng.choice(cols_ok, size=cn_degs[i], replace=False)
+        used[cs] = True
+        for c in sorted(cs):
+            lines.append(f"{i} {c}")
+    # make sure the highest column index appears so that nc is what we asked for
+    if not used[nc - 1]:
+        lines.append(f"{mc - 1} {nc - 1}") if f"{mc - 1} {nc - 1}" not in lines else None
+    open(path, "w").write("\n".join(lines))
+    return path
+
+
+CASES = [
+    # name, nc, mc, CN degree pool, puncture, shorten, skipped columns, expected residency
+    ("lds_small_irregular", 300, 150, [2, 3, 4], (5, 6, 7), (), (), "lds"),
+    ("lds_wide_cn", 600, 200, [5, 6, 7, 8], (), (10, 11), (3,), "lds"),
+    ("mem_cn12", 900, 100, [9, 12, 16], (), (), (), "memory"),
+    ("reg_tile_8x4", 9000, 6000, [3, 4], (1, 2, 3), (), (7,), "registers"),
+    ("reg_tile_2x8", 3000, 2000, [8], (), (), (), "registers"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_random_code_bit_exact(case, tmp_path):
+    import libldpc_amd
+    name, nc, mc, pool, punct, short, skip, residency = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    degs = rng.choice(pool, size=mc)
+    path = make_code(str(tmp_path / f"{name}.txt"), nc, mc, degs, rng, punct, short, skip)
+    code = orc.Code(path)
+    d = libldpc_amd.HipDecoder(path)
+    assert (d.nc, d.mc, d.nnz) == (code.nc, code.mc, code.nnz)
+    if residency:
+        assert d.residency == residency, d.residency
+    # channel points chosen so that some frames converge and some do not
+    for ch, x, ms, early, iters in (("AWGN", 3.0, False, True, 20), ("AWGN", 1.0, True, True, 15),
+                                    ("AWGN", 2.0, False, False, 4), ("BSC", 0.03, False, True, 20),
+                                    ("BEC", 0.25, False, True, 20)):
+        if ch == "BEC" and d.residency != "lds" and d.nnz > 100000:
+            continue
+        d.set_bec_compat(False)
+        d.stream_begin(ch, 3, x)
+        d.stream_skip(1)
+        r = d.stream_decode(5, early_term=early, iterations=iters, decoding="BP_MS" if ms else "BP", want=OUT)
+        o = code.run_frames(ch, x, seed=3, skip=1, count=5, min_sum=ms, early_term=early, iters=iters,
+                            math=orc.MATH_DET, bec_compat=False)
+        for k in OUT:
+            assert np.array_equal(r[k], o[k].astype(r[k].dtype)), (name, ch, x, k)
+
+
+def test_edge_case_batches():
+    import libldpc_amd
+    d = libldpc_amd.HipDecoder(orc.H_TXT)
+    code = orc.Code(orc.H_TXT)
+    # zero iterations: the decoder returns 0 and leaves its zero-initialised estimate (decoder.cpp:21-22)
+    d.stream_begin("AWGN", 0, -4.0)
+    r = d.stream_decode(3, iterations=0, want=OUT)
+    o = code.run_frames("AWGN", -4.0, seed=0, count=3, iters=0, math=orc.MATH_DET)
+    for k in ("iters", "bit_errors", "hard", "llr_in"):
+        assert np.array_equal(r[k], o[k].astype(r[k].dtype)), k
+    # one iteration, one frame
+    d.stream_begin("AWGN", 0, -4.0)
+    r = d.stream_decode(1, iterations=1, want=OUT)
+    o = code.run_frames("AWGN", -4.0, seed=0, count=1, iters=1, math=orc.MATH_DET)
+    for k in OUT:
+        assert np.array_equal(r[k], o[k].astype(r[k].dtype)), k
+    # empty batch
+    r = d.stream_decode(0, want=("iters",))
+    assert r["iters"].shape == (0,)
+    assert d.decode_batch(np.zeros((0, d.nc)))["iters"].shape == (0,)

@@ -102,11 +102,19 @@ def main():
     rank, local_rank, world = shard.rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal on a one-GPU box (tests only): LDPC_BENCH_ONE_GPU=1 puts every rank on cuda:0 and
+    # LDPC_BENCH_BACKEND=gloo carries the counter reduce over gloo; the driver's runs use neither
+    if os.environ.get("LDPC_BENCH_ONE_GPU"):
+        local_rank = 0
+    backend = os.environ.get("LDPC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     early = not args.no_early_term
     B, K, W = args.batch, args.steps, args.warmup
@@ -128,6 +136,8 @@ def main():
     def step():
         dec.stream_decode(B, early_term=early, iterations=ITERS, decoding=args.decoding, want=(), out=out, stream=stream)
         c = shard.counters_from_outputs(torch, iters_d, be_d, ITERS, early)
+        if dist is not None and backend != "nccl":
+            return shard.reduce_counters(c.cpu(), dist).to(dev)
         return shard.reduce_counters(c, dist)  # the one collective of the path: 5 x int64 over xGMI
 
     tot = torch.zeros(5, dtype=torch.int64, device=dev)
@@ -155,7 +165,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: block descriptors load as scalars
     const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
 
     if (tid == 0)
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void bec_kernel(const BecArgs a)
     uint8_t *msg = reinterpret_cast<uint8_t *>(lds);
     uint8_t *sym = msg + ((nnz + 15) / 16) * 16;
     uint8_t *lout = sym + ((nc + 15) / 16) * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t frame = blockIdx.x;
     const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
     auto cw_of_rank = [&](int r) -> uint8_t { return cw ? cw[P.rank_col[r]] : 0; };

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
     uint8_t *hbm = reinterpret_cast<uint8_t *>(mb + R.mb_doubles);
     const DevPlan &P = a.plan;
     const int nc = P.nc;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t frame = blockIdx.x;
     double *llr = a.ws_llr + frame * nc;
     uint8_t *hard = a.ws_hb + frame * nc;

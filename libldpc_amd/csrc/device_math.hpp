@@ -8,9 +8,40 @@
 #include <hip/hip_runtime.h>
 
 #include "detmath.h"
+#include "plan.hpp"
 
 namespace ldpc_amd
 {
+
+// Wave-uniform table reads: a pointer re-typed into the constant address space lets the compiler fetch
+// block descriptors and work lists with scalar loads (s_load_*) into SGPRs instead of per-lane vector loads.
+template <typename T>
+using const_as_ptr = const T __attribute__((address_space(4))) *;
+
+template <typename T>
+__device__ __forceinline__ const_as_ptr<T> uniform_table(const T *p)
+{
+    return (const_as_ptr<T>)(reinterpret_cast<uintptr_t>(p));
+}
+
+// block descriptors (plan.hpp) read dword by dword through the scalar path
+template <typename B>
+__device__ __forceinline__ B load_block2(const B *table, uint32_t i) // {u32, u16, u16}
+{
+    static_assert(sizeof(B) == 8, "descriptor layout");
+    const auto t = uniform_table(reinterpret_cast<const uint32_t *>(table));
+    const uint32_t w0 = t[2 * i], w1 = t[2 * i + 1];
+    return B{w0, static_cast<uint16_t>(w1 & 0xFFFFu), static_cast<uint16_t>(w1 >> 16)};
+}
+
+template <typename B>
+__device__ __forceinline__ B load_block3(const B *table, uint32_t i) // {u32, u32, u16, u16}
+{
+    static_assert(sizeof(B) == 12, "descriptor layout");
+    const auto t = uniform_table(reinterpret_cast<const uint32_t *>(table));
+    const uint32_t w0 = t[3 * i], w1 = t[3 * i + 1], w2 = t[3 * i + 2];
+    return B{w0, w1, static_cast<uint16_t>(w2 & 0xFFFFu), static_cast<uint16_t>(w2 >> 16)};
+}
 
 // decoder.h:7-10 — sign(x) = 1 - 2*signbit(x)
 __device__ __forceinline__ int sgn(double x) { return 1 - 2 * static_cast<int>(__builtin_signbit(x) != 0); }

@@ -157,14 +157,14 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
     }
 
     // ---- v2c initialisation: decoder.cpp:16-19 ----
-    const uint16_t *my_vn = P.vn_work + wave * P.vn_work_stride;
-    const uint16_t *my_cn = P.cn_work + wave * P.cn_work_stride;
+    const auto my_vn = uniform_table(P.vn_work + wave * P.vn_work_stride);
+    const auto my_cn = uniform_table(P.cn_work + wave * P.cn_work_stride);
     for (int w = 0; w < P.vn_work_stride; ++w)
     {
-        uint16_t bi = my_vn[w];
+        const uint32_t bi = my_vn[w];
         if (bi == 0xFFFF)
             break;
-        const VnBlock b = P.vn_blocks[bi];
+        const VnBlock b = load_block3(P.vn_blocks, bi);
         if (lane < b.count)
         {
             double L = llr[b.first + lane];
@@ -182,20 +182,20 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
         // ---- CN pass: decoder.cpp:25-45 ----
         for (int w = 0; w < P.cn_work_stride; ++w)
         {
-            uint16_t bi = my_cn[w];
+            const uint32_t bi = my_cn[w];
             if (bi == 0xFFFF)
                 break;
-            cn_block<MINSUM, MAXD>(msg, P.cn_blocks[bi], lane);
+            cn_block<MINSUM, MAXD>(msg, load_block2(P.cn_blocks, bi), lane);
         }
         __syncthreads();
 
         // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
         for (int w = 0; w < P.vn_work_stride; ++w)
         {
-            uint16_t bi = my_vn[w];
+            const uint32_t bi = my_vn[w];
             if (bi == 0xFFFF)
                 break;
-            const VnBlock b = P.vn_blocks[bi];
+            const VnBlock b = load_block3(P.vn_blocks, bi);
             if (lane < b.count)
             {
                 const int r = b.first + lane;
@@ -222,10 +222,10 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
             int bad = 0;
             for (int w = 0; w < P.cn_work_stride; ++w)
             {
-                uint16_t bi = my_cn[w];
+                const uint32_t bi = my_cn[w];
                 if (bi == 0xFFFF)
                     break;
-                const CnBlock b = P.cn_blocks[bi];
+                const CnBlock b = load_block2(P.cn_blocks, bi);
                 if (lane < b.count)
                 {
                     int par = 0;
@@ -354,15 +354,15 @@ __global__ __launch_bounds__(kThreads) void bec_kernel(const BecArgs a)
     for (int r = tid; r < nc; r += kThreads)
         lout[r] = 0; // mLLROut starts zeroed
 
-    const uint16_t *my_vn = P.vn_work + wave * P.vn_work_stride;
-    const uint16_t *my_cn = P.cn_work + wave * P.cn_work_stride;
+    const auto my_vn = uniform_table(P.vn_work + wave * P.vn_work_stride);
+    const auto my_cn = uniform_table(P.cn_work + wave * P.cn_work_stride);
     // v2c init: decoder.cpp:96-99
     for (int w = 0; w < P.vn_work_stride; ++w)
     {
-        uint16_t bi = my_vn[w];
+        const uint32_t bi = my_vn[w];
         if (bi == 0xFFFF)
             break;
-        const VnBlock b = P.vn_blocks[bi];
+        const VnBlock b = load_block3(P.vn_blocks, bi);
         if (lane < b.count)
         {
             uint8_t L = sym[b.first + lane];
@@ -379,10 +379,10 @@ __global__ __launch_bounds__(kThreads) void bec_kernel(const BecArgs a)
         // ---- CN update: decoder.cpp:105-123 ----
         for (int w = 0; w < P.cn_work_stride; ++w)
         {
-            uint16_t bi = my_cn[w];
+            const uint32_t bi = my_cn[w];
             if (bi == 0xFFFF)
                 break;
-            const CnBlock b = P.cn_blocks[bi];
+            const CnBlock b = load_block2(P.cn_blocks, bi);
             if (lane < b.count)
             {
                 uint8_t *m = msg + b.off + lane;
@@ -412,10 +412,10 @@ __global__ __launch_bounds__(kThreads) void bec_kernel(const BecArgs a)
         int any_e = 0;
         for (int w = 0; w < P.vn_work_stride; ++w)
         {
-            uint16_t bi = my_vn[w];
+            const uint32_t bi = my_vn[w];
             if (bi == 0xFFFF)
                 break;
-            const VnBlock b = P.vn_blocks[bi];
+            const VnBlock b = load_block3(P.vn_blocks, bi);
             if (lane < b.count)
             {
                 const int r = b.first + lane;

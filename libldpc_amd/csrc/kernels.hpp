@@ -18,8 +18,8 @@ struct DevPlan
     const CnBlock *cn_blocks;
     const VnBlock *vn_blocks;
     const uint32_t *vn_slot;
-    const uint16_t *cn_work;
-    const uint16_t *vn_work;
+    const uint32_t *cn_work;
+    const uint32_t *vn_work;
     const uint32_t *col_rank;
     const uint32_t *rank_col;
     const uint32_t *tx_rank;

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
     for (int k = 0; k < KC; ++k)
     {
         deg[k] = R.cn_deg[k * kRegWaves + wave];
-        have[k] = lane < R.cn_cnt[k * kRegWaves + wave];
+        have[k] = lane < static_cast<int>(R.cn_cnt[k * kRegWaves + wave]);
 #pragma unroll
         for (int j = 0; j < MAXD; ++j)
             m[k][j] = 0.0;
@@ -125,9 +125,9 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
     // ---- v2c initialisation (decoder.cpp:16-19): every edge starts with its VN's input LLR ----
     for (int r = 0; r < R.rounds; ++r)
     {
-        for (uint32_t b = R.round_first[r] + wave; b < R.round_first[r + 1]; b += kRegWaves)
+        for (uint32_t b = uniform_table(R.round_first)[r] + wave; b < uniform_table(R.round_first)[r + 1]; b += kRegWaves)
         {
-            const RegVnBlock vb = R.vn_blocks[b];
+            const RegVnBlock vb = load_block3(R.vn_blocks, b);
             if (lane < vb.count)
             {
                 const double L = llr[vb.first + lane];
@@ -176,9 +176,9 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
                 }
             __syncthreads();
             // ---- VN pass, APP and hard decision (decoder.cpp:48-64) on this round's VN blocks ----
-            for (uint32_t b = R.round_first[r] + wave; b < R.round_first[r + 1]; b += kRegWaves)
+            for (uint32_t b = uniform_table(R.round_first)[r] + wave; b < uniform_table(R.round_first)[r + 1]; b += kRegWaves)
             {
-                const RegVnBlock vb = R.vn_blocks[b];
+                const RegVnBlock vb = load_block3(R.vn_blocks, b);
                 if (lane < vb.count)
                 {
                     const int rank = vb.first + lane;

@@ -11,17 +11,17 @@ namespace ldpc_amd
 namespace
 {
 // longest-processing-time assignment of weighted blocks to waves
-void deal(const std::vector<int> &cost, std::vector<uint16_t> &work, int &stride)
+void deal(const std::vector<int> &cost, std::vector<uint32_t> &work, int &stride)
 {
     std::vector<int> order(cost.size());
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-    std::vector<std::vector<uint16_t>> lists(kDecodeWaves);
+    std::vector<std::vector<uint32_t>> lists(kDecodeWaves);
     std::vector<long> load(kDecodeWaves, 0);
     for (int b : order)
     {
         int w = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
-        lists[w].push_back(static_cast<uint16_t>(b));
+        lists[w].push_back(static_cast<uint32_t>(b));
         load[w] += cost[b];
     }
     stride = 1;

@@ -55,8 +55,8 @@ struct Plan
     std::vector<CnBlock> cn_blocks;
     std::vector<VnBlock> vn_blocks;
     std::vector<uint32_t> vn_slot;   // slot of the p-th edge (column file order) of each VN
-    std::vector<uint16_t> cn_work;   // [kDecodeWaves][cn_work_stride] block ids, 0xFFFF = none
-    std::vector<uint16_t> vn_work;   // [kDecodeWaves][vn_work_stride]
+    std::vector<uint32_t> cn_work;   // [kDecodeWaves][cn_work_stride] block ids, 0xFFFF = none
+    std::vector<uint32_t> vn_work;   // [kDecodeWaves][vn_work_stride]
     int cn_work_stride = 0, vn_work_stride = 0;
     std::vector<uint32_t> col_rank;  // column -> VN rank
     std::vector<uint32_t> rank_col;  // VN rank -> column

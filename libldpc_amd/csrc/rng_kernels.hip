@@ -51,26 +51,52 @@ __device__ __forceinline__ void mt_regenerate(uint64_t *x, int lane)
     }
 }
 
-__global__ __launch_bounds__(64) void mt_generate_kernel(const uint64_t *states, uint64_t *next_last,
-                                                         uint64_t *out, uint32_t chunk_words)
+// One workgroup of three waves per chunk.  The twist has 156-way parallelism: words 0..155 of the next
+// window depend only on the current window, words 156..311 on the current window and the new words 0..155.
+// Thread t < 156 produces words t and t+156; reads and writes of a half are separated by workgroup barriers.
+constexpr int kGenThreads = 192;
+__global__ __launch_bounds__(kGenThreads) void mt_generate_kernel(const uint64_t *states, uint64_t *next_last,
+                                                                  uint64_t *out, uint32_t chunk_words)
 {
     __shared__ uint64_t x[kMtN];
-    const int lane = threadIdx.x;
+    const int t = threadIdx.x;
+    const bool act = t < 156;
     const uint64_t c = blockIdx.x;
     const uint64_t *s = states + c * kMtN;
-    for (int k = lane; k < kMtN; k += 64)
+    for (int k = t; k < kMtN; k += kGenThreads)
         x[k] = s[k];
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     uint64_t *o = out + c * chunk_words;
     const uint32_t blocks = chunk_words / kMtN;
     for (uint32_t b = 0; b < blocks; ++b)
     {
-        for (int k = lane; k < kMtN; k += 64)
-            o[b * kMtN + k] = mt_temper(x[k]);
-        mt_regenerate(x, lane);
+        uint64_t lo = 0, hi = 0, lo1 = 0, hi1 = 0;
+        if (act)
+        {
+            lo = x[t], hi = x[t + 156];
+            lo1 = x[t + 1];                           // t+1 <= 156
+            hi1 = t + 157 < kMtN ? x[t + 157] : 0;    // word 312 wraps to the NEW word 0, taken below
+            o[b * kMtN + t] = mt_temper(lo);
+            o[b * kMtN + 156 + t] = mt_temper(hi);
+        }
+        __syncthreads();
+        uint64_t nlo = 0;
+        if (act)
+        {
+            nlo = mt_twist(lo, lo1, hi); // x[k+156] of the current window
+            x[t] = nlo;
+        }
+        __syncthreads();
+        if (act)
+        {
+            if (t == 155)
+                hi1 = x[0]; // new word 0
+            x[t + 156] = mt_twist(hi, hi1, nlo); // (k+156) mod 312 = k-156: the new low half
+        }
+        __syncthreads();
     }
     if (next_last && c + 1 == gridDim.x) // the window after the last chunk = start state of the next chunk
-        for (int k = lane; k < kMtN; k += 64)
+        for (int k = t; k < kMtN; k += kGenThreads)
             next_last[k] = x[k];
 }
 
@@ -283,7 +309,7 @@ int launch_mt_generate(const uint64_t *states, uint64_t *next_last, uint64_t *ou
         return hipSuccess;
     if (chunk_words % kMtN != 0)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mt_generate_kernel, dim3(n_chunks), dim3(64), 0, static_cast<hipStream_t>(stream), states,
+    hipLaunchKernelGGL(mt_generate_kernel, dim3(n_chunks), dim3(kGenThreads), 0, static_cast<hipStream_t>(stream), states,
                        next_last, out, chunk_words);
     return hipGetLastError();
 }

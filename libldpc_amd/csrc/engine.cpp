@@ -378,16 +378,21 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), s), "event");
     if (plan_.lds_ok)
     {
-        // Input LLRs stay in LDS.  Moving them to memory (LDPC_AMD_LLR_MEM=1) frees room for a fifth resident
-        // frame per CU on the n=1024 code, but the extra memory reads cost what the occupancy gains (measured).
-        bool llr_mem = false;
-        if (const char *e = std::getenv("LDPC_AMD_LLR_MEM"))
-            llr_mem = e[0] == '1';
-        if (llr_mem)
+        // Input LLRs: in registers when that frees the LDS for one more resident frame per CU (n=1024 code:
+        // 40 KB -> 31 KB, five frames instead of four) and the plan allows it; in LDS otherwise.  Device memory
+        // (mode 1) also reaches five frames but pays for it in memory reads (measured: no net gain).
+        const size_t cu_lds = 160 * 1024, with_llr = plan_.lds_bytes, without = plan_.lds_bytes - 8 * nc;
+        int llr_mode = 0;
+        if (cu_lds / without > cu_lds / with_llr && plan_.vn_work_stride <= 8 && !plan_.has_isolated_vn &&
+            plan_.nc <= plan_.nnz)
+            llr_mode = 2;
+        if (const char *e = std::getenv("LDPC_AMD_LLR_MODE"))
+            llr_mode = std::atoi(e);
+        if (llr_mode == 1)
             a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
         if (const char *e = std::getenv("LDPC_AMD_LDS_PAD")) // occupancy experiments: extra dynamic LDS per frame
             a.plan.lds_bytes += static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) & ~15u;
-        check(launch_decode_lds(a, p.min_sum, plan_.max_cn_degree, s), "decode (LDS-resident)");
+        check(launch_decode_lds(a, p.min_sum, plan_.max_cn_degree, llr_mode, s), "decode (LDS-resident)");
     }
     else if (reg_plan_.ok && !std::getenv("LDPC_AMD_NO_REG"))
     {

@@ -105,8 +105,14 @@ __device__ __forceinline__ int wave_sum(int v)
 // ---------------------------------------------------------------------------------------------
 // MAXD = widest check node the instantiation handles (4, 8 or 16): the register allocation of a kernel is
 // that of its widest CN update, so narrow codes get a leaner kernel.
-// LLR_IN_LDS = false keeps the input LLRs (read once per VN per iteration) in memory instead of LDS.
-template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, bool LLR_IN_LDS>
+// LLR_MODE = where the input LLRs (read once per VN per iteration) live: kLlrLds, kLlrMem (device memory), or
+// kLlrRegs: every lane keeps the LLRs of the <= kMaxVnBlocksInRegs variable nodes it serves in registers — VN
+// blocks are dealt to waves once per code, so lane (wave, l) always serves the same nodes.  Without the LLR
+// array the n=1024 code needs 31 KB of LDS per frame instead of 40 KB: five resident frames per CU, not four.
+enum : int { kLlrLds = 0, kLlrMem = 1, kLlrRegs = 2 };
+constexpr int kMaxVnBlocksInRegs = 8;
+
+template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE>
 __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 {
     extern __shared__ double lds[];
@@ -119,14 +125,16 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
     if constexpr (LDS_RESIDENT)
     {
         msg = lds;
-        if constexpr (LLR_IN_LDS)
+        if constexpr (LLR_MODE == kLlrLds)
         {
             llr = lds + nnz;
             hb = reinterpret_cast<uint8_t *>(llr + nc);
         }
         else
         {
-            llr = a.ws_llr + frame * nc;
+            // kLlrRegs: the channel writes the LLRs into the (still unused) message array, from where each lane
+            // picks up its own before the v2c initialisation overwrites it (nc <= nnz: no isolated VN)
+            llr = LLR_MODE == kLlrMem ? a.ws_llr + frame * nc : lds;
             hb = reinterpret_cast<uint8_t *>(lds + nnz);
         }
     }
@@ -156,23 +164,65 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
             o[P.rank_col[r]] = llr[r];
     }
 
-    // ---- v2c initialisation: decoder.cpp:16-19 ----
     const auto my_vn = uniform_table(P.vn_work + wave * P.vn_work_stride);
     const auto my_cn = uniform_table(P.cn_work + wave * P.cn_work_stride);
-    for (int w = 0; w < P.vn_work_stride; ++w)
+    double my_llr[kMaxVnBlocksInRegs];
+    if constexpr (LLR_MODE == kLlrRegs)
     {
-        const uint32_t bi = my_vn[w];
-        if (bi == 0xFFFF)
-            break;
-        const VnBlock b = load_block3(P.vn_blocks, bi);
-        if (lane < b.count)
+#pragma unroll
+        for (int w = 0; w < kMaxVnBlocksInRegs; ++w)
         {
-            double L = llr[b.first + lane];
-            const uint32_t *idx = P.vn_slot + b.idx_off + lane;
-            for (int p = 0; p < b.degree; ++p)
-                msg[idx[p * b.count]] = L;
+            my_llr[w] = 0.0;
+            if (w < P.vn_work_stride)
+            {
+                const uint32_t bi = my_vn[w];
+                if (bi != 0xFFFF)
+                {
+                    const VnBlock b = load_block3(P.vn_blocks, bi);
+                    if (lane < b.count)
+                        my_llr[w] = llr[b.first + lane];
+                }
+            }
         }
+        __syncthreads(); // every lane holds its LLRs: the message array may now be written
     }
+    // the w-th VN block of this wave: body(block, input LLR of this lane's node)
+    auto for_my_vn_blocks = [&](auto &&body) {
+        if constexpr (LLR_MODE == kLlrRegs)
+        {
+#pragma unroll
+            for (int w = 0; w < kMaxVnBlocksInRegs; ++w)
+            {
+                if (w >= P.vn_work_stride)
+                    break;
+                const uint32_t bi = my_vn[w];
+                if (bi == 0xFFFF)
+                    break;
+                const VnBlock b = load_block3(P.vn_blocks, bi);
+                if (lane < b.count)
+                    body(b, my_llr[w]);
+            }
+        }
+        else
+        {
+            for (int w = 0; w < P.vn_work_stride; ++w)
+            {
+                const uint32_t bi = my_vn[w];
+                if (bi == 0xFFFF)
+                    break;
+                const VnBlock b = load_block3(P.vn_blocks, bi);
+                if (lane < b.count)
+                    body(b, llr[b.first + lane]);
+            }
+        }
+    };
+
+    // ---- v2c initialisation: decoder.cpp:16-19 ----
+    for_my_vn_blocks([&](const VnBlock &b, double L) {
+        const uint32_t *idx = P.vn_slot + b.idx_off + lane;
+        for (int p = 0; p < b.degree; ++p)
+            msg[idx[p * b.count]] = L;
+    });
     __syncthreads();
 
     double *out_llr = WANT_LLR ? a.llr_out + frame * nc : nullptr;
@@ -190,30 +240,21 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
         __syncthreads();
 
         // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
-        for (int w = 0; w < P.vn_work_stride; ++w)
-        {
-            const uint32_t bi = my_vn[w];
-            if (bi == 0xFFFF)
-                break;
-            const VnBlock b = load_block3(P.vn_blocks, bi);
-            if (lane < b.count)
+        for_my_vn_blocks([&](const VnBlock &b, double L) {
+            const uint32_t *idx = P.vn_slot + b.idx_off + lane;
+            double out = L;
+            for (int p = 0; p < b.degree; ++p) // sequential sum in column file order
+                out += msg[idx[p * b.count]];
+            const uint8_t bit = out <= 0;
+            for (int p = 0; p < b.degree; ++p)
             {
-                const int r = b.first + lane;
-                const uint32_t *idx = P.vn_slot + b.idx_off + lane;
-                double out = llr[r];
-                for (int p = 0; p < b.degree; ++p) // sequential sum in column file order
-                    out += msg[idx[p * b.count]];
-                const uint8_t bit = out <= 0;
-                for (int p = 0; p < b.degree; ++p)
-                {
-                    const uint32_t s = idx[p * b.count];
-                    msg[s] = out - msg[s];
-                    hb[s] = bit;
-                }
-                if constexpr (WANT_LLR)
-                    out_llr[P.rank_col[r]] = out;
+                const uint32_t s = idx[p * b.count];
+                msg[s] = out - msg[s];
+                hb[s] = bit;
             }
-        }
+            if constexpr (WANT_LLR)
+                out_llr[P.rank_col[b.first + lane]] = out;
+        });
         __syncthreads();
 
         // ---- syndrome early termination: decoder.cpp:66-72, decoder.h:47-64 ----
@@ -248,7 +289,10 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
         if (!ran)
             return 0; // mCO is still zero-initialised when no iteration ran
         uint32_t s0 = P.rank_slot0[r];
-        return s0 != kNoSlot ? hb[s0] : static_cast<int>(llr[r] <= 0);
+        if constexpr (LLR_MODE == kLlrRegs)
+            return hb[s0]; // this mode is only used for codes without isolated variable nodes
+        else
+            return s0 != kNoSlot ? hb[s0] : static_cast<int>(llr[r] <= 0);
     };
     if (a.hard)
     {
@@ -261,7 +305,7 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
         if (!ran)
             for (int r = tid; r < nc; r += kThreads)
                 out_llr[P.rank_col[r]] = 0.0;
-        else // isolated variable nodes never pass through a VN block with edges
+        else if constexpr (LLR_MODE != kLlrRegs) // isolated variable nodes never pass through a VN block with edges
             for (int r = tid; r < nc; r += kThreads)
                 if (P.rank_slot0[r] == kNoSlot)
                     out_llr[P.rank_col[r]] = llr[r];
@@ -584,17 +628,17 @@ __global__ __launch_bounds__(256) void encode_cw_kernel(const EncodeArgs a, uint
     }
 }
 
-template <bool LDS_RESIDENT, int MAXD, bool LLR_IN_LDS>
+template <bool LDS_RESIDENT, int MAXD, int LLR_MODE>
 int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *stream)
 {
     const bool want_llr = a.llr_out != nullptr;
     void (*k)(const DecodeArgs) = nullptr;
     if (min_sum)
-        k = want_llr ? decode_kernel<true, true, LDS_RESIDENT, MAXD, LLR_IN_LDS>
-                     : decode_kernel<true, false, LDS_RESIDENT, MAXD, LLR_IN_LDS>;
+        k = want_llr ? decode_kernel<true, true, LDS_RESIDENT, MAXD, LLR_MODE>
+                     : decode_kernel<true, false, LDS_RESIDENT, MAXD, LLR_MODE>;
     else
-        k = want_llr ? decode_kernel<false, true, LDS_RESIDENT, MAXD, LLR_IN_LDS>
-                     : decode_kernel<false, false, LDS_RESIDENT, MAXD, LLR_IN_LDS>;
+        k = want_llr ? decode_kernel<false, true, LDS_RESIDENT, MAXD, LLR_MODE>
+                     : decode_kernel<false, false, LDS_RESIDENT, MAXD, LLR_MODE>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));
     if (e != hipSuccess)
@@ -606,18 +650,31 @@ int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *s
 
 } // namespace
 
-int launch_decode_lds(const DecodeArgs &a, bool min_sum, int max_cn_degree, void *stream)
+int launch_decode_lds(const DecodeArgs &a, bool min_sum, int max_cn_degree, int llr_mode, void *stream)
 {
     if (a.n_frames == 0)
         return hipSuccess;
-    const bool llr_mem = a.ws_llr != nullptr;
-    const uint32_t lds = a.plan.lds_bytes - (llr_mem ? 8u * static_cast<uint32_t>(a.plan.nc) : 0u);
+    if (llr_mode == kLlrMem && !a.ws_llr)
+        return hipErrorInvalidValue;
+    if (llr_mode == kLlrRegs && (a.plan.vn_work_stride > kMaxVnBlocksInRegs || a.plan.nc > a.plan.nnz))
+        return hipErrorInvalidValue;
+    const uint32_t lds = a.plan.lds_bytes - (llr_mode != kLlrLds ? 8u * static_cast<uint32_t>(a.plan.nc) : 0u);
+#define LDPC_PICK(D)                                                              \
+    switch (llr_mode)                                                             \
+    {                                                                             \
+    case kLlrMem: return launch_decode<true, D, kLlrMem>(a, min_sum, lds, stream);   \
+    case kLlrRegs: return launch_decode<true, D, kLlrRegs>(a, min_sum, lds, stream); \
+    default: return launch_decode<true, D, kLlrLds>(a, min_sum, lds, stream);        \
+    }
     if (max_cn_degree <= 4)
-        return llr_mem ? launch_decode<true, 4, false>(a, min_sum, lds, stream)
-                       : launch_decode<true, 4, true>(a, min_sum, lds, stream);
+    {
+        LDPC_PICK(4)
+    }
     if (max_cn_degree <= 8)
-        return llr_mem ? launch_decode<true, 8, false>(a, min_sum, lds, stream)
-                       : launch_decode<true, 8, true>(a, min_sum, lds, stream);
+    {
+        LDPC_PICK(8)
+    }
+#undef LDPC_PICK
     return hipErrorInvalidValue;
 }
 
@@ -628,11 +685,11 @@ int launch_decode_mem(const DecodeArgs &a, bool min_sum, int max_cn_degree, uint
     if (!a.ws_msg || !a.ws_llr || !a.ws_hb)
         return hipErrorInvalidValue;
     if (max_cn_degree <= 4)
-        return launch_decode<false, 4, false>(a, min_sum, occupancy_lds, stream);
+        return launch_decode<false, 4, kLlrMem>(a, min_sum, occupancy_lds, stream);
     if (max_cn_degree <= 8)
-        return launch_decode<false, 8, false>(a, min_sum, occupancy_lds, stream);
+        return launch_decode<false, 8, kLlrMem>(a, min_sum, occupancy_lds, stream);
     if (max_cn_degree <= 16)
-        return launch_decode<false, 16, false>(a, min_sum, occupancy_lds, stream);
+        return launch_decode<false, 16, kLlrMem>(a, min_sum, occupancy_lds, stream);
     return hipErrorInvalidValue;
 }
 

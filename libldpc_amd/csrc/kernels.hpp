@@ -101,8 +101,9 @@ struct BecArgs
 };
 
 // All launchers enqueue on `stream` (hipStream_t passed as void*) and return a hipError_t as int.
-// LDS-resident decoder; a.ws_llr != nullptr keeps the input LLRs in memory instead of LDS
-int launch_decode_lds(const DecodeArgs &a, bool min_sum, int max_cn_degree, void *stream);
+// LDS-resident decoder; llr_mode: 0 input LLRs in LDS, 1 in device memory (a.ws_llr), 2 in registers
+// (needs plan.vn_work_stride <= 8 and no isolated variable node)
+int launch_decode_lds(const DecodeArgs &a, bool min_sum, int max_cn_degree, int llr_mode, void *stream);
 // memory-resident variant for codes whose messages do not fit LDS (a.ws_* must be set); occupancy_lds
 // bytes of dynamic LDS are requested only to bound the number of resident frames per CU
 int launch_decode_mem(const DecodeArgs &a, bool min_sum, int max_cn_degree, uint32_t occupancy_lds, void *stream);

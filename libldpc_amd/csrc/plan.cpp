@@ -91,6 +91,7 @@ Plan build_plan(const LdpcCode &code)
         vn_cost.push_back(2 * d + 2);
         i = j;
     }
+    p.has_isolated_vn = p.nc > 0 && cdeg(cols[p.nc - 1]) == 0; // sorted by degree, descending
     p.rank_slot0.assign(p.nc, kNoSlot);
     for (int r = 0; r < p.nc; ++r)
         if (cdeg(cols[r]) > 0)

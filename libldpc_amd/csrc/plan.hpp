@@ -68,6 +68,7 @@ struct Plan
     size_t lds_bytes = 0;            // dynamic LDS the LDS-resident kernel needs per frame
     bool lds_ok = false;             // fits the LDS-resident kernel's limits
     bool hbm_ok = false;             // within the memory-resident kernel's limits
+    bool has_isolated_vn = false;    // a column without any edge
 };
 
 // ---- register-resident decoder (codes too large for 4 frames of LDS per CU, e.g. n=8192) ----------------

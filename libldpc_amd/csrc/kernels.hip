@@ -117,6 +117,7 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 {
     extern __shared__ double lds[];
     __shared__ int misc[4];
+    __shared__ int votes[2][kDecodeWaves];
     const DevPlan &P = a.plan;
     const int nnz = P.nnz, nc = P.nc;
     const uint64_t frame = blockIdx.x;
@@ -275,7 +276,18 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
                     bad |= par;
                 }
             }
-            if (!__syncthreads_or(bad))
+            // workgroup-wide OR with one barrier: every wave posts its vote in a slot of the iteration's parity
+            // (slots alternate, so the next iteration's votes cannot overtake a slow reader)
+            const int ph = I & 1;
+            const bool wave_bad = __ballot(bad != 0) != 0;
+            if (lane == 0)
+                votes[ph][wave] = wave_bad;
+            __syncthreads();
+            int any = 0;
+#pragma unroll
+            for (int w = 0; w < kDecodeWaves; ++w)
+                any |= votes[ph][w];
+            if (!any)
                 break;
         }
         ++I;

@@ -262,6 +262,15 @@ Engine::~Engine()
     for (void *e : ev_)
         if (e)
             (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+    for (int i = 0; i < 2; ++i)
+    {
+        if (ev_pairs_ready_[i])
+            (void)hipEventDestroy(static_cast<hipEvent_t>(ev_pairs_ready_[i]));
+        if (ev_pairs_free_[i])
+            (void)hipEventDestroy(static_cast<hipEvent_t>(ev_pairs_free_[i]));
+    }
+    if (rng_stream_)
+        (void)hipStreamDestroy(static_cast<hipStream_t>(rng_stream_));
 }
 
 void Engine::set_profiling(bool on)
@@ -418,6 +427,11 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         throw std::runtime_error("check-node degree above " + std::to_string(kMaxCnDegree) + " is not supported");
     if (profiling_)
         check(hipEventRecord(static_cast<hipEvent_t>(ev_[1]), s), "event");
+    if (a.mode == kModeAwgn && a.pairs_buffer >= 0 && ev_pairs_free_[a.pairs_buffer])
+    {
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_free_[a.pairs_buffer]), s), "event");
+        pairs_in_use_[a.pairs_buffer] = true;
+    }
     if (out.codeword)
     {
         if (a.codeword)
@@ -590,13 +604,33 @@ uint64_t Engine::stream_raw_draws() const { return raw_next_; }
 // Locate the accepted polar pairs that supply the normals of frames [frame_pos_, frame_pos_+n).
 void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream)
 {
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t user = static_cast<hipStream_t>(stream);
+    if (!rng_stream_)
+    {
+        // non-blocking: no implicit ordering with the caller's (possibly default) stream
+        hipStream_t rs;
+        check(hipStreamCreateWithFlags(&rs, hipStreamNonBlocking), "hipStreamCreate");
+        rng_stream_ = rs;
+        for (int i = 0; i < 2; ++i)
+        {
+            hipEvent_t e0, e1;
+            check(hipEventCreateWithFlags(&e0, hipEventDisableTiming), "hipEventCreate");
+            check(hipEventCreateWithFlags(&e1, hipEventDisableTiming), "hipEventCreate");
+            ev_pairs_ready_[i] = e0, ev_pairs_free_[i] = e1;
+        }
+    }
+    hipStream_t s = static_cast<hipStream_t>(rng_stream_);
+    const int buf = pp_;
+    pp_ ^= 1;
+    // the decode kernel that last read this pairs buffer (two batches ago) must be done before it is refilled
+    if (pairs_in_use_[buf])
+        check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev_pairs_free_[buf]), 0), "wait pairs free");
     const uint64_t nct = static_cast<uint64_t>(plan_.nct);
     const uint64_t g0 = frame_pos_ * nct, g1 = g0 + n * nct; // normals [g0, g1)
     const uint64_t q_hi = (g1 - 1) >> 1;
     const uint64_t want = q_hi + 1 - pair_next_;
-    // pairs_[0] holds the carry pair (rank pair_next_-1), new pairs follow
-    uint64_t *pairs = static_cast<uint64_t *>(pairs_.reserve(16 * (want + 1)));
+    // pairs[0] holds the carry pair (rank pair_next_-1), new pairs follow
+    uint64_t *pairs = static_cast<uint64_t *>(pairs_[buf].reserve(16 * (want + 1)));
     uint64_t *carry = static_cast<uint64_t *>(carry_.reserve(16));
     if (pair_next_ > 0)
         check(hipMemcpyAsync(pairs, carry, 16, hipMemcpyDeviceToDevice, s), "carry in");
@@ -608,14 +642,14 @@ void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream)
         check(hipEventRecord(static_cast<hipEvent_t>(ev_[2]), s), "event");
     for (;;)
     {
-        const uint64_t *raw = noise_.generate(raw_next_, 2 * trials, stream);
+        const uint64_t *raw = noise_.generate(raw_next_, 2 * trials, s);
         tr.mark("generate(enqueue)");
         const uint32_t n_blocks = static_cast<uint32_t>((trials + kScanBlock - 1) / kScanBlock);
         uint32_t *counts = static_cast<uint32_t *>(scan_counts_.reserve(4 * static_cast<size_t>(n_blocks)));
         uint64_t *offs = static_cast<uint64_t *>(scan_offsets_.reserve(8 * static_cast<size_t>(n_blocks)));
         check(launch_polar_scan(raw, trials, want, counts, offs, pairs + 2, res, s), "polar_scan");
         check(hipMemcpyAsync(&h, res, sizeof h, hipMemcpyDeviceToHost, s), "scan result");
-        check(hipStreamSynchronize(s), "sync");
+        check(hipStreamSynchronize(s), "sync"); // waits for the noise-stream kernels only, not for the caller's decode
         tr.mark("scan+sync");
         if (h.enough)
             break;
@@ -624,11 +658,14 @@ void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream)
     if (profiling_)
         check(hipEventRecord(static_cast<hipEvent_t>(ev_[3]), s), "event");
     check(hipMemcpyAsync(carry, pairs + 2 * want, 16, hipMemcpyDeviceToDevice, s), "carry out");
+    check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_ready_[buf]), s), "event");
+    check(hipStreamWaitEvent(user, static_cast<hipEvent_t>(ev_pairs_ready_[buf]), 0), "wait pairs ready");
     a.pairs = pairs;
     a.pair_base = pair_next_ - 1; // wraps to 2^64-1 for the very first batch: q - pair_base == q + 1
     a.normal_base = g0;
     a.sigma = sigma_, a.sigma2 = sigma2_;
     a.shorten_llr = 99999.9; // channel.cpp:83
+    a.pairs_buffer = buf;
     pair_next_ += want;
     raw_next_ += 2 * h.trials_used;
 }

@@ -149,7 +149,13 @@ class Engine
     DeviceBuffer cw_run_, cw_next_, cw_frames_, cw_before_, enc_prefix_;
     uint64_t last_enc_n_ = 0;   // frames of the last encode_frames call that produced cw_frames_
     const uint32_t *g_col_ptr_ = nullptr, *g_col_row_ = nullptr;
-    DeviceBuffer pairs_, carry_, scan_counts_, scan_offsets_, scan_result_;
+    DeviceBuffer pairs_[2], carry_, scan_counts_, scan_offsets_, scan_result_;
+    // the AWGN noise-stream kernels run on their own stream so that the pairs of batch s+1 are located while
+    // the decode kernel of batch s drains; pairs_ is double-buffered, events order the two streams
+    void *rng_stream_ = nullptr;
+    void *ev_pairs_ready_[2] = {nullptr, nullptr}, *ev_pairs_free_[2] = {nullptr, nullptr};
+    bool pairs_in_use_[2] = {false, false};
+    int pp_ = 0;
     DeviceBuffer stage_in_, stage_iters_, stage_be_, stage_hard_, stage_llr_out_, stage_llr_in_, stage_cw_;
     DeviceBuffer ws_msg_, ws_llr_, ws_hb_;
     bool profiling_ = false;

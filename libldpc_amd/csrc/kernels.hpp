@@ -50,6 +50,7 @@ struct DecodeArgs
     const uint64_t *pairs;
     uint64_t pair_base;
     uint64_t normal_base; // index of this batch's first normal in the stream
+    int pairs_buffer;     // host bookkeeping: which of the engine's two pairs buffers `pairs` points into
     double sigma, sigma2; // sqrt(sigma2), sigma2 = 10^(-snr/10)
     double shorten_llr;   // 99999.9 (AWGN) or delta (BSC)
     // kModeBsc: raw draws, one per transmitted bit: raw[frame*nct + i]

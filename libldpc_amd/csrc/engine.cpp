@@ -259,7 +259,10 @@ Engine::~Engine()
 {
     for (void *p : owned_)
         (void)hipFree(p);
-    for (void *e : ev_)
+    for (auto &q : prof_pending_)
+        for (void *e : q)
+            prof_free_.push_back(e);
+    for (void *e : prof_free_)
         if (e)
             (void)hipEventDestroy(static_cast<hipEvent_t>(e));
     for (int i = 0; i < 2; ++i)
@@ -273,33 +276,55 @@ Engine::~Engine()
         (void)hipStreamDestroy(static_cast<hipStream_t>(rng_stream_));
 }
 
-void Engine::set_profiling(bool on)
+void Engine::set_profiling(bool on) { profiling_ = on; }
+
+// Event pairs are queued per launch and only read back in last_ms(), so that profiling does not serialise
+// the noise stream of batch s+1 behind the decode of batch s.
+void Engine::prof_mark(int which, void *stream)
 {
-    profiling_ = on;
-    if (on)
-        for (auto &e : ev_)
-            if (!e)
-            {
-                hipEvent_t ev;
-                check(hipEventCreate(&ev), "hipEventCreate");
-                e = ev;
-            }
+    if (!profiling_)
+        return;
+    auto &q = prof_pending_[which];
+    if (q.size() >= 8192 && q.size() % 2 == 0) // nobody is reading: keep the queue bounded
+    {
+        prof_free_.insert(prof_free_.end(), q.begin(), q.end());
+        q.clear();
+    }
+    void *e;
+    if (prof_free_.empty())
+    {
+        hipEvent_t ev;
+        check(hipEventCreate(&ev), "hipEventCreate");
+        e = ev;
+    }
+    else
+    {
+        e = prof_free_.back();
+        prof_free_.pop_back();
+    }
+    check(hipEventRecord(static_cast<hipEvent_t>(e), static_cast<hipStream_t>(stream)), "event");
+    q.push_back(e);
 }
 
+// mean duration (ms) of the launches of kind `which` (0 decode kernel, 1 noise stream) since the previous call
 float Engine::last_ms(int which)
 {
-    if (!ev_[0])
-        return 0.f;
-    hipEvent_t a = static_cast<hipEvent_t>(ev_[which ? 2 : 0]), b = static_cast<hipEvent_t>(ev_[which ? 3 : 1]);
-    if (hipEventSynchronize(b) != hipSuccess)
-        return 0.f;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, a, b) != hipSuccess)
+    auto &q = prof_pending_[which ? 1 : 0];
+    double sum = 0;
+    size_t spans = 0;
+    for (size_t i = 0; i + 1 < q.size(); i += 2)
     {
-        (void)hipGetLastError();
-        return 0.f;
+        hipEvent_t a = static_cast<hipEvent_t>(q[i]), b = static_cast<hipEvent_t>(q[i + 1]);
+        float ms = 0.f;
+        if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess)
+            sum += ms, ++spans;
+        else
+            (void)hipGetLastError();
     }
-    return ms;
+    for (void *e : q)
+        prof_free_.push_back(e);
+    q.clear();
+    return spans ? static_cast<float>(sum / spans) : 0.f;
 }
 
 void Engine::upload_plan()
@@ -383,8 +408,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
     a.hard = st.route(out.hard, stage_hard_, n * nc);
     a.llr_out = st.route(out.llr_out, stage_llr_out_, 8 * n * nc);
     a.llr_in_dump = st.route(out.llr_in, stage_llr_in_, 8 * n * nc);
-    if (profiling_)
-        check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), s), "event");
+    prof_mark(0, s);
     if (plan_.lds_ok)
     {
         // Input LLRs: in registers when that frees the LDS for one more resident frame per CU (n=1024 code:
@@ -425,8 +449,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
     }
     else
         throw std::runtime_error("check-node degree above " + std::to_string(kMaxCnDegree) + " is not supported");
-    if (profiling_)
-        check(hipEventRecord(static_cast<hipEvent_t>(ev_[1]), s), "event");
+    prof_mark(0, s);
     if (a.mode == kModeAwgn && a.pairs_buffer >= 0 && ev_pairs_free_[a.pairs_buffer])
     {
         check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_free_[a.pairs_buffer]), s), "event");
@@ -468,11 +491,9 @@ void Engine::run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const 
     a.hard = st.route(out.hard, stage_hard_, n * nc);
     a.llr_out = st.route(out.llr_out, stage_llr_out_, 8 * n * nc);
     a.llr_in_dump = st.route(out.llr_in, stage_llr_in_, 8 * n * nc);
-    if (profiling_)
-        check(hipEventRecord(static_cast<hipEvent_t>(ev_[0]), s), "event");
+    prof_mark(0, s);
     check(launch_bec(a, s), "bec");
-    if (profiling_)
-        check(hipEventRecord(static_cast<hipEvent_t>(ev_[1]), s), "event");
+    prof_mark(0, s);
     if (out.codeword)
     {
         if (codeword)
@@ -638,8 +659,7 @@ void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream)
     uint64_t trials = static_cast<uint64_t>(want * 1.2732395447351628 + 8.0 * std::sqrt(static_cast<double>(want)) + 256);
     ScanResult h{};
     PhaseTrace tr;
-    if (profiling_)
-        check(hipEventRecord(static_cast<hipEvent_t>(ev_[2]), s), "event");
+    prof_mark(1, s);
     for (;;)
     {
         const uint64_t *raw = noise_.generate(raw_next_, 2 * trials, s);
@@ -655,8 +675,7 @@ void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream)
             break;
         trials += trials / 8 + 4096; // vanishingly rare: take a longer look at the same stream
     }
-    if (profiling_)
-        check(hipEventRecord(static_cast<hipEvent_t>(ev_[3]), s), "event");
+    prof_mark(1, s);
     check(hipMemcpyAsync(carry, pairs + 2 * want, 16, hipMemcpyDeviceToDevice, s), "carry out");
     check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_ready_[buf]), s), "event");
     check(hipStreamWaitEvent(user, static_cast<hipEvent_t>(ev_pairs_ready_[buf]), 0), "wait pairs ready");

@@ -159,7 +159,8 @@ class Engine
     DeviceBuffer stage_in_, stage_iters_, stage_be_, stage_hard_, stage_llr_out_, stage_llr_in_, stage_cw_;
     DeviceBuffer ws_msg_, ws_llr_, ws_hb_;
     bool profiling_ = false;
-    void *ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<void *> prof_pending_[2], prof_free_; // hipEvent_t: begin/end pairs per launch, spare events
+    void prof_mark(int which, void *stream);
 };
 
 std::string hip_error_string(int err);

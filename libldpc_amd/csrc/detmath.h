@@ -287,4 +287,32 @@ DM_FN double dm_e_to_llr(uint32_t sign_word, double e)
 /* sign carried as the upper word of the double (bit 31 = sign); signs combine by xor of these words */
 #define DM_SIGN_WORD(x) ((uint32_t)(dm_bits(x) >> 32))
 
+/* ------------------------------------------------------------------------------------------------
+ * Likelihood-ratio form of the whole BP iteration (no exp/log inside the loop).
+ *
+ * With rho(L) = e^L and lambda(L) = e^-L the reference's two updates are, as real functions,
+ *   variable node (decoder.cpp:48-64):  lambda(total)  = lambda(L_ch) * prod_p lambda(c2v_p)
+ *                                       rho(v2c_p)     = lambda(c2v_p) / lambda(total)
+ *   check node    (decoder.cpp:25-45):  rho(x [+] y)    = (1 + rho(x) rho(y)) / (rho(x) + rho(y))
+ *                                       lambda(x [+] y) = (rho(x) + rho(y)) / (1 + rho(x) rho(y))
+ * so v2c messages are carried as rho, c2v messages as lambda; an iteration costs one IEEE division per
+ * c2v message and one per variable node, and every operand is positive: no cancellation, the relative error
+ * of a ratio (= the absolute error of its LLR) stays at a few 1e-16 per operation.
+ *
+ * binary64 holds e^L only for |L| < 709, so this form is valid while every message stays inside
+ * [DM_RATIO_LO, DM_RATIO_HI] = 2^-+240 (|L| <= 166.3) and every channel LLR within DM_RATIO_LLR_LIMIT; a
+ * frame that leaves that box at any point is decoded from scratch with the LLR-domain form above (dm_boxplus /
+ * dm_e_combine).  The rule is per frame and depends on nothing but the frame's own data.  Products of up to
+ * four in-range factors stay normal numbers (2^-+960); longer products are range-checked every third factor.
+ * ------------------------------------------------------------------------------------------------ */
+#define DM_RATIO_HI 0x1p240
+#define DM_RATIO_LO 0x1p-240
+#define DM_RATIO_LLR_LIMIT 166.0
+
+DM_FN int dm_ratio_out_of_range(double r) { return !(r <= DM_RATIO_HI && r >= DM_RATIO_LO); } /* NaN: out */
+DM_FN double dm_ratio_rho(double x, double y) { return DM_FMA(x, y, 1.0) / (x + y); }
+DM_FN double dm_ratio_lambda(double x, double y) { return (x + y) / DM_FMA(x, y, 1.0); }
+/* the same two with one operand given as a fraction n/d (a partial result not yet divided) */
+DM_FN double dm_ratio_lambda_frac(double n, double d, double y) { return DM_FMA(d, y, n) / DM_FMA(n, y, d); }
+
 #endif /* LDPC_AMD_DETMATH_H */

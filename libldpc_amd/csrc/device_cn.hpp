@@ -71,4 +71,53 @@ __device__ __forceinline__ void cn_core(double (&v)[D])
         v[j] = boxplus<MINSUM>(F[j - 1], B[j + 1]);
 }
 
+// Likelihood-ratio form of the same recursion (detmath.h, "Likelihood-ratio form"): v[j] = rho(v2c_j) on entry,
+// lambda(c2v_j) on return.  Partial results F[j], B[j] are carried as rho; the last box-plus of every output is
+// taken directly in lambda form, so a degree-3 node costs three divisions and a degree-4 node four (its two
+// partial results stay undivided fractions).
+template <int D>
+__device__ __forceinline__ void cn_ratio(double (&v)[D])
+{
+    if constexpr (D == 2)
+    {
+        const double a = 1.0 / v[1], b = 1.0 / v[0];
+        v[0] = a, v[1] = b;
+    }
+    else if constexpr (D == 3)
+    {
+        const double o0 = dm_ratio_lambda(v[2], v[1]); // B[1] = B[2] [+] v[1]
+        const double o1 = dm_ratio_lambda(v[0], v[2]); // F[0] [+] B[2]
+        const double o2 = dm_ratio_lambda(v[0], v[1]); // F[1] = F[0] [+] v[1]
+        v[0] = o0, v[1] = o1, v[2] = o2;
+    }
+    else if constexpr (D == 4)
+    {
+        const double nF = DM_FMA(v[0], v[1], 1.0), dF = v[0] + v[1]; // F[1] = nF / dF
+        const double nB = DM_FMA(v[3], v[2], 1.0), dB = v[3] + v[2]; // B[2] = nB / dB
+        const double o0 = dm_ratio_lambda_frac(nB, dB, v[1]);        // B[1] = B[2] [+] v[1]
+        const double o1 = dm_ratio_lambda_frac(nB, dB, v[0]);        // F[0] [+] B[2]
+        const double o2 = dm_ratio_lambda_frac(nF, dF, v[3]);        // F[1] [+] B[3]
+        const double o3 = dm_ratio_lambda_frac(nF, dF, v[2]);        // F[2] = F[1] [+] v[2]
+        v[0] = o0, v[1] = o1, v[2] = o2, v[3] = o3;
+    }
+    else
+    {
+        double F[D], B[D];
+        F[0] = v[0];
+        B[D - 1] = v[D - 1];
+#pragma unroll
+        for (int j = 1; j <= D - 3; ++j)
+            F[j] = dm_ratio_rho(F[j - 1], v[j]);
+#pragma unroll
+        for (int j = D - 2; j >= 2; --j)
+            B[j] = dm_ratio_rho(B[j + 1], v[j]);
+        const double o0 = dm_ratio_lambda(B[2], v[1]);
+        const double oL = dm_ratio_lambda(F[D - 3], v[D - 2]);
+#pragma unroll
+        for (int j = 1; j < D - 1; ++j)
+            v[j] = dm_ratio_lambda(F[j - 1], B[j + 1]);
+        v[0] = o0, v[D - 1] = oL;
+    }
+}
+
 } // namespace ldpc_amd

@@ -409,46 +409,63 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
     a.llr_out = st.route(out.llr_out, stage_llr_out_, 8 * n * nc);
     a.llr_in_dump = st.route(out.llr_in, stage_llr_in_, 8 * n * nc);
     prof_mark(0, s);
-    if (plan_.lds_ok)
-    {
-        // Input LLRs: in registers when that frees the LDS for one more resident frame per CU (n=1024 code:
-        // 40 KB -> 31 KB, five frames instead of four) and the plan allows it; in LDS otherwise.  Device memory
-        // (mode 1) also reaches five frames but pays for it in memory reads (measured: no net gain).
-        const size_t cu_lds = 160 * 1024, with_llr = plan_.lds_bytes, without = plan_.lds_bytes - 8 * nc;
-        int llr_mode = 0;
-        if (cu_lds / without > cu_lds / with_llr && plan_.vn_work_stride <= 8 && !plan_.has_isolated_vn &&
-            plan_.nc <= plan_.nnz)
-            llr_mode = 2;
-        if (const char *e = std::getenv("LDPC_AMD_LLR_MODE"))
-            llr_mode = std::atoi(e);
-        if (llr_mode == 1)
+    const auto launch = [&] {
+        if (plan_.lds_ok)
+        {
+            // Input LLRs: in registers when that frees the LDS for one more resident frame per CU (n=1024 code:
+            // 40 KB -> 31 KB, five frames instead of four) and the plan allows it; in LDS otherwise.  Device memory
+            // (mode 1) also reaches five frames but pays for it in memory reads (measured: no net gain).
+            const size_t cu_lds = 160 * 1024, with_llr = plan_.lds_bytes, without = plan_.lds_bytes - 8 * nc;
+            int llr_mode = 0;
+            if (cu_lds / without > cu_lds / with_llr && plan_.vn_work_stride <= 8 && !plan_.has_isolated_vn &&
+                plan_.nc <= plan_.nnz)
+                llr_mode = 2;
+            if (const char *e = std::getenv("LDPC_AMD_LLR_MODE"))
+                llr_mode = std::atoi(e);
+            if (llr_mode == 1)
+                a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
+            if (const char *e = std::getenv("LDPC_AMD_LDS_PAD")) // occupancy experiments: extra dynamic LDS per frame
+                a.plan.lds_bytes = dev_.lds_bytes + (static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) & ~15u);
+            check(launch_decode_lds(a, p.min_sum, plan_.max_cn_degree, llr_mode, s), "decode (LDS-resident)");
+        }
+        else if (reg_plan_.ok && !std::getenv("LDPC_AMD_NO_REG"))
+        {
             a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
-        if (const char *e = std::getenv("LDPC_AMD_LDS_PAD")) // occupancy experiments: extra dynamic LDS per frame
-            a.plan.lds_bytes += static_cast<uint32_t>(std::strtoul(e, nullptr, 10)) & ~15u;
-        check(launch_decode_lds(a, p.min_sum, plan_.max_cn_degree, llr_mode, s), "decode (LDS-resident)");
-    }
-    else if (reg_plan_.ok && !std::getenv("LDPC_AMD_NO_REG"))
+            a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nc));
+            check(launch_decode_reg(a, dev_reg_, p.min_sum, s), "decode (register-resident)");
+        }
+        else if (plan_.hbm_ok)
+        {
+            a.ws_msg = static_cast<double *>(ws_msg_.reserve(8 * n * nnz));
+            a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
+            a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nnz));
+            // resident frames per CU are bounded through a dummy LDS request so that the frames in flight
+            // (256 CUs x frames/CU x state bytes) stay inside the 256 MiB Infinity Cache
+            const uint64_t per_frame = 8ull * nnz + 8ull * nc + nnz;
+            uint64_t frames_per_cu = std::clamp<uint64_t>((224ull << 20) / (256 * per_frame), 1, 8);
+            if (const char *e = std::getenv("LDPC_AMD_FRAMES_PER_CU"))
+                frames_per_cu = std::clamp<uint64_t>(std::strtoull(e, nullptr, 10), 1, 8);
+            const uint32_t occ_lds = frames_per_cu >= 8 ? 0 : static_cast<uint32_t>((160 * 1024) / (frames_per_cu + 1) + 1024) & ~15u;
+            check(launch_decode_mem(a, p.min_sum, plan_.max_cn_degree, occ_lds, s), "decode (memory-resident)");
+        }
+        else
+            throw std::runtime_error("check-node degree above " + std::to_string(kMaxCnDegree) + " is not supported");
+    };
+    // Sum-product with early termination runs in likelihood-ratio form (detmath.h: no exp/log inside the
+    // iteration); the few frames whose values leave the box that form can represent come back in a list and are
+    // decoded from scratch by the LLR-domain form.  Which form finishes a frame depends on that frame's data
+    // only, never on the batch it travels in.  (LDPC_AMD_NO_RATIO: experiments only — results change by ulps.)
+    if (!p.min_sum && p.early_term && p.iterations > 0 && !std::getenv("LDPC_AMD_NO_RATIO"))
     {
-        a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
-        a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nc));
-        check(launch_decode_reg(a, dev_reg_, p.min_sum, s), "decode (register-resident)");
+        uint32_t *redo = static_cast<uint32_t *>(redo_.reserve(4 * (n + 1)));
+        check(hipMemsetAsync(redo, 0, 4, s), "redo count");
+        a.redo_count = redo, a.redo_list = redo + 1;
+        launch();
+        a.redo_count = nullptr, a.redo_list = nullptr;
+        a.redo_count_in = redo, a.redo_list_in = redo + 1;
     }
-    else if (plan_.hbm_ok)
-    {
-        a.ws_msg = static_cast<double *>(ws_msg_.reserve(8 * n * nnz));
-        a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
-        a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nnz));
-        // resident frames per CU are bounded through a dummy LDS request so that the frames in flight
-        // (256 CUs x frames/CU x state bytes) stay inside the 256 MiB Infinity Cache
-        const uint64_t per_frame = 8ull * nnz + 8ull * nc + nnz;
-        uint64_t frames_per_cu = std::clamp<uint64_t>((224ull << 20) / (256 * per_frame), 1, 8);
-        if (const char *e = std::getenv("LDPC_AMD_FRAMES_PER_CU"))
-            frames_per_cu = std::clamp<uint64_t>(std::strtoull(e, nullptr, 10), 1, 8);
-        const uint32_t occ_lds = frames_per_cu >= 8 ? 0 : static_cast<uint32_t>((160 * 1024) / (frames_per_cu + 1) + 1024) & ~15u;
-        check(launch_decode_mem(a, p.min_sum, plan_.max_cn_degree, occ_lds, s), "decode (memory-resident)");
-    }
-    else
-        throw std::runtime_error("check-node degree above " + std::to_string(kMaxCnDegree) + " is not supported");
+    launch();
+    a.redo_count_in = nullptr, a.redo_list_in = nullptr;
     prof_mark(0, s);
     if (a.mode == kModeAwgn && a.pairs_buffer >= 0 && ev_pairs_free_[a.pairs_buffer])
     {

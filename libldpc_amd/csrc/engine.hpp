@@ -158,6 +158,7 @@ class Engine
     int pp_ = 0;
     DeviceBuffer stage_in_, stage_iters_, stage_be_, stage_hard_, stage_llr_out_, stage_llr_in_, stage_cw_;
     DeviceBuffer ws_msg_, ws_llr_, ws_hb_;
+    DeviceBuffer redo_; // [0] = count, [1..] = frames handed back by the ratio-form launch
     bool profiling_ = false;
     std::vector<void *> prof_pending_[2], prof_free_; // hipEvent_t: begin/end pairs per launch, spare events
     void prof_mark(int which, void *stream);

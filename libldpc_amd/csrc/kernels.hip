@@ -33,20 +33,23 @@ constexpr int kThreads = kDecodeWaves * kWaveSize;
 constexpr uint8_t kErasure = 'E'; // functions.h:105
 
 // check-node update on the frame's message array: slot(j) = m[j*stride] (decoder.cpp:25-45, device_cn.hpp)
-template <int D, bool MINSUM>
+template <int D, bool MINSUM, bool RATIO>
 __device__ __forceinline__ void cn_update(double *m, int stride)
 {
     double v[D];
 #pragma unroll
     for (int j = 0; j < D; ++j)
         v[j] = m[j * stride];
-    cn_core<D, MINSUM>(v);
+    if constexpr (RATIO)
+        cn_ratio<D>(v);
+    else
+        cn_core<D, MINSUM>(v);
 #pragma unroll
     for (int j = 0; j < D; ++j)
         m[j * stride] = v[j];
 }
 
-template <bool MINSUM, int MAXD>
+template <bool MINSUM, int MAXD, bool RATIO>
 __device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane)
 {
     if (lane >= b.count)
@@ -55,18 +58,18 @@ __device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane)
     const int s = b.count;
     switch (b.degree) // wave-uniform
     {
-    case 2: cn_update<2, MINSUM>(m, s); break;
-    case 3: cn_update<3, MINSUM>(m, s); break;
-    case 4: cn_update<4, MINSUM>(m, s); break;
+    case 2: cn_update<2, MINSUM, RATIO>(m, s); break;
+    case 3: cn_update<3, MINSUM, RATIO>(m, s); break;
+    case 4: cn_update<4, MINSUM, RATIO>(m, s); break;
     default:
         if constexpr (MAXD > 4)
         {
             switch (b.degree)
             {
-            case 5: cn_update<5, MINSUM>(m, s); break;
-            case 6: cn_update<6, MINSUM>(m, s); break;
-            case 7: cn_update<7, MINSUM>(m, s); break;
-            case 8: cn_update<8, MINSUM>(m, s); break;
+            case 5: cn_update<5, MINSUM, RATIO>(m, s); break;
+            case 6: cn_update<6, MINSUM, RATIO>(m, s); break;
+            case 7: cn_update<7, MINSUM, RATIO>(m, s); break;
+            case 8: cn_update<8, MINSUM, RATIO>(m, s); break;
             default: break;
             }
         }
@@ -74,14 +77,14 @@ __device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane)
         {
             switch (b.degree)
             {
-            case 9: cn_update<9, MINSUM>(m, s); break;
-            case 10: cn_update<10, MINSUM>(m, s); break;
-            case 11: cn_update<11, MINSUM>(m, s); break;
-            case 12: cn_update<12, MINSUM>(m, s); break;
-            case 13: cn_update<13, MINSUM>(m, s); break;
-            case 14: cn_update<14, MINSUM>(m, s); break;
-            case 15: cn_update<15, MINSUM>(m, s); break;
-            case 16: cn_update<16, MINSUM>(m, s); break;
+            case 9: cn_update<9, MINSUM, RATIO>(m, s); break;
+            case 10: cn_update<10, MINSUM, RATIO>(m, s); break;
+            case 11: cn_update<11, MINSUM, RATIO>(m, s); break;
+            case 12: cn_update<12, MINSUM, RATIO>(m, s); break;
+            case 13: cn_update<13, MINSUM, RATIO>(m, s); break;
+            case 14: cn_update<14, MINSUM, RATIO>(m, s); break;
+            case 15: cn_update<15, MINSUM, RATIO>(m, s); break;
+            case 16: cn_update<16, MINSUM, RATIO>(m, s); break;
             default: break;
             }
         }
@@ -112,15 +115,26 @@ __device__ __forceinline__ int wave_sum(int v)
 enum : int { kLlrLds = 0, kLlrMem = 1, kLlrRegs = 2 };
 constexpr int kMaxVnBlocksInRegs = 8;
 
-template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE>
+// RATIO = the likelihood-ratio form of the sum-product iteration (detmath.h): v2c messages are rho = e^L, c2v
+// messages lambda = e^-L, the input LLRs are kept as lambda.  A frame whose values leave the representable box
+// is not finished here: its index goes to a.redo_list and the LLR-domain instantiation decodes it from scratch
+// in a second launch (a.redo_list_in / a.redo_count_in).
+template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO>
 __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 {
+    static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
     extern __shared__ double lds[];
     __shared__ int misc[4];
     __shared__ int votes[2][kDecodeWaves];
     const DevPlan &P = a.plan;
     const int nnz = P.nnz, nc = P.nc;
-    const uint64_t frame = blockIdx.x;
+    uint64_t frame = blockIdx.x;
+    if (a.redo_count_in) // second pass: only the frames the ratio form handed back
+    {
+        if (blockIdx.x >= *uniform_table(a.redo_count_in))
+            return;
+        frame = uniform_table(a.redo_list_in)[blockIdx.x];
+    }
     double *msg, *llr;
     uint8_t *hb;
     if constexpr (LDS_RESIDENT)
@@ -167,6 +181,19 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 
     const auto my_vn = uniform_table(P.vn_work + wave * P.vn_work_stride);
     const auto my_cn = uniform_table(P.cn_work + wave * P.cn_work_stride);
+    int escaped = 0; // RATIO: some value of this frame left the representable box
+    if constexpr (RATIO && LLR_MODE != kLlrRegs)
+    {
+        // input LLRs become lambda = e^-L in place (isolated variable nodes keep their LLR: nothing multiplies it)
+        for (int r = tid; r < nc; r += kThreads)
+            if (P.rank_slot0[r] != kNoSlot)
+            {
+                const double L = llr[r];
+                escaped |= !(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT);
+                llr[r] = dm_exp(0.0 - L);
+            }
+        __syncthreads();
+    }
     double my_llr[kMaxVnBlocksInRegs];
     if constexpr (LLR_MODE == kLlrRegs)
     {
@@ -181,7 +208,14 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
                 {
                     const VnBlock b = load_block3(P.vn_blocks, bi);
                     if (lane < b.count)
+                    {
                         my_llr[w] = llr[b.first + lane];
+                        if constexpr (RATIO)
+                        {
+                            escaped |= !(__builtin_fabs(my_llr[w]) <= DM_RATIO_LLR_LIMIT);
+                            my_llr[w] = dm_exp(0.0 - my_llr[w]);
+                        }
+                    }
                 }
             }
         }
@@ -221,8 +255,9 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
     // ---- v2c initialisation: decoder.cpp:16-19 ----
     for_my_vn_blocks([&](const VnBlock &b, double L) {
         const uint32_t *idx = P.vn_slot + b.idx_off + lane;
+        const double v0 = RATIO ? 1.0 / L : L; // RATIO: L is lambda(L_ch), the first v2c is rho(L_ch)
         for (int p = 0; p < b.degree; ++p)
-            msg[idx[p * b.count]] = L;
+            msg[idx[p * b.count]] = v0;
     });
     __syncthreads();
 
@@ -236,13 +271,41 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
             const uint32_t bi = my_cn[w];
             if (bi == 0xFFFF)
                 break;
-            cn_block<MINSUM, MAXD>(msg, load_block2(P.cn_blocks, bi), lane);
+            cn_block<MINSUM, MAXD, RATIO>(msg, load_block2(P.cn_blocks, bi), lane);
         }
         __syncthreads();
 
         // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
         for_my_vn_blocks([&](const VnBlock &b, double L) {
             const uint32_t *idx = P.vn_slot + b.idx_off + lane;
+            if constexpr (RATIO)
+            {
+                // lambda(total) = lambda(L_ch) * prod lambda(c2v_p), in column file order
+                double prod = L;
+                if (b.degree <= 3)
+                    for (int p = 0; p < b.degree; ++p)
+                        prod *= msg[idx[p * b.count]];
+                else
+                    for (int p = 0; p < b.degree; ++p)
+                    {
+                        prod *= msg[idx[p * b.count]];
+                        if (p % 3 == 2)
+                            escaped |= dm_ratio_out_of_range(prod);
+                    }
+                const uint8_t bit = prod >= 1.0; // total LLR <= 0
+                const double tot = 1.0 / prod;   // rho(total)
+                for (int p = 0; p < b.degree; ++p)
+                {
+                    const uint32_t s = idx[p * b.count];
+                    const double o = tot * msg[s]; // rho(total - c2v_p)
+                    escaped |= dm_ratio_out_of_range(o);
+                    msg[s] = o;
+                    hb[s] = bit;
+                }
+                if constexpr (WANT_LLR)
+                    out_llr[P.rank_col[b.first + lane]] = 0.0 - dm_log(prod);
+                return;
+            }
             double out = L;
             for (int p = 0; p < b.degree; ++p) // sequential sum in column file order
                 out += msg[idx[p * b.count]];
@@ -279,14 +342,23 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
             // workgroup-wide OR with one barrier: every wave posts its vote in a slot of the iteration's parity
             // (slots alternate, so the next iteration's votes cannot overtake a slow reader)
             const int ph = I & 1;
-            const bool wave_bad = __ballot(bad != 0) != 0;
+            int wave_vote = __ballot(bad != 0) != 0;
+            if constexpr (RATIO)
+                wave_vote |= (__ballot(escaped != 0) != 0) << 1;
             if (lane == 0)
-                votes[ph][wave] = wave_bad;
+                votes[ph][wave] = wave_vote;
             __syncthreads();
             int any = 0;
 #pragma unroll
             for (int w = 0; w < kDecodeWaves; ++w)
                 any |= votes[ph][w];
+            if constexpr (RATIO)
+                if (any & 2) // checked before the syndrome: an escaped frame's hard decisions mean nothing
+                {
+                    if (tid == 0)
+                        a.redo_list[atomicAdd(a.redo_count, 1u)] = static_cast<uint32_t>(frame);
+                    return;
+                }
             if (!any)
                 break;
         }
@@ -644,13 +716,19 @@ template <bool LDS_RESIDENT, int MAXD, int LLR_MODE>
 int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *stream)
 {
     const bool want_llr = a.llr_out != nullptr;
+    const bool ratio = a.redo_list != nullptr;
+    if (ratio && (min_sum || !a.early_term || a.iterations == 0 || !a.redo_count || a.redo_count_in))
+        return hipErrorInvalidValue;
     void (*k)(const DecodeArgs) = nullptr;
     if (min_sum)
-        k = want_llr ? decode_kernel<true, true, LDS_RESIDENT, MAXD, LLR_MODE>
-                     : decode_kernel<true, false, LDS_RESIDENT, MAXD, LLR_MODE>;
+        k = want_llr ? decode_kernel<true, true, LDS_RESIDENT, MAXD, LLR_MODE, false>
+                     : decode_kernel<true, false, LDS_RESIDENT, MAXD, LLR_MODE, false>;
+    else if (ratio)
+        k = want_llr ? decode_kernel<false, true, LDS_RESIDENT, MAXD, LLR_MODE, true>
+                     : decode_kernel<false, false, LDS_RESIDENT, MAXD, LLR_MODE, true>;
     else
-        k = want_llr ? decode_kernel<false, true, LDS_RESIDENT, MAXD, LLR_MODE>
-                     : decode_kernel<false, false, LDS_RESIDENT, MAXD, LLR_MODE>;
+        k = want_llr ? decode_kernel<false, true, LDS_RESIDENT, MAXD, LLR_MODE, false>
+                     : decode_kernel<false, false, LDS_RESIDENT, MAXD, LLR_MODE, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));
     if (e != hipSuccess)

@@ -68,6 +68,13 @@ struct DecodeArgs
     double *ws_msg;  // [n_frames][nnz]
     double *ws_llr;  // [n_frames][nc]
     uint8_t *ws_hb;  // [n_frames][nnz]
+    // sum-product in likelihood-ratio form (detmath.h): when redo_list is set the launch runs that form and
+    // appends the frames it could not finish to redo_list[atomicAdd(redo_count)]; a launch with redo_list_in /
+    // redo_count_in set decodes exactly those frames (block b takes frame redo_list_in[b], b < *redo_count_in)
+    uint32_t *redo_list;
+    uint32_t *redo_count;
+    const uint32_t *redo_list_in;
+    const uint32_t *redo_count_in;
 };
 
 // device copy of RegPlan (register-resident decoder, kernels_reg.hip)

@@ -29,7 +29,7 @@ namespace ldpc_amd
 namespace
 {
 
-template <bool MINSUM, int MAXD>
+template <bool MINSUM, bool RATIO, int MAXD>
 __device__ __forceinline__ void cn_regs(double (&m)[MAXD], int degree)
 {
     // wave-uniform degree: one fully unrolled recursion per width
@@ -38,7 +38,10 @@ __device__ __forceinline__ void cn_regs(double (&m)[MAXD], int degree)
     {                                        \
         double v[D];                         \
         _Pragma("unroll") for (int j = 0; j < D; ++j) v[j] = m[j]; \
-        cn_core<D, MINSUM>(v);               \
+        if constexpr (RATIO)                 \
+            cn_ratio<D>(v);                  \
+        else                                 \
+            cn_core<D, MINSUM>(v);           \
         _Pragma("unroll") for (int j = 0; j < D; ++j) m[j] = v[j]; \
         break;                               \
     }
@@ -82,9 +85,12 @@ __device__ __forceinline__ int wave_sum_i(int v)
     return v;
 }
 
-template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD>
+// RATIO: the likelihood-ratio form of the sum-product iteration, exactly as in kernels.hip (v2c = rho, c2v = lambda,
+// input LLRs kept as lambda; frames that leave the representable box go to a.redo_list).
+template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, bool RATIO>
 __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, const DevRegPlan R)
 {
+    static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
     constexpr int kRegWaves = NT / 64;
     extern __shared__ double mb[]; // mailbox: mb_doubles doubles, then mb_doubles hard-bit bytes
     __shared__ int misc[4];
@@ -92,7 +98,13 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
     const DevPlan &P = a.plan;
     const int nc = P.nc;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t frame = blockIdx.x;
+    uint64_t frame = blockIdx.x;
+    if (a.redo_count_in) // second pass: only the frames the ratio form handed back
+    {
+        if (blockIdx.x >= *uniform_table(a.redo_count_in))
+            return;
+        frame = uniform_table(a.redo_list_in)[blockIdx.x];
+    }
     double *llr = a.ws_llr + frame * nc;
     uint8_t *hard = a.ws_hb + frame * nc;
     const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
@@ -106,6 +118,19 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
         double *o = a.llr_in_dump + frame * nc;
         for (int r = tid; r < nc; r += NT)
             o[P.rank_col[r]] = llr[r];
+    }
+    int escaped = 0; // RATIO: some value of this frame left the representable box
+    if constexpr (RATIO)
+    {
+        // input LLRs become lambda = e^-L in place (isolated variable nodes keep their LLR)
+        for (int r = tid; r < nc; r += NT)
+            if (P.rank_slot0[r] != kNoSlot)
+            {
+                const double L = llr[r];
+                escaped |= !(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT);
+                llr[r] = dm_exp(0.0 - L);
+            }
+        __syncthreads();
     }
 
     double m[KC][MAXD];
@@ -131,8 +156,9 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
             if (lane < vb.count)
             {
                 const double L = llr[vb.first + lane];
+                const double v0 = RATIO ? 1.0 / L : L; // RATIO: L is lambda(L_ch), the first v2c is rho(L_ch)
                 for (int p = 0; p < vb.degree; ++p)
-                    mb[vb.mb_off + p * vb.count + lane] = L;
+                    mb[vb.mb_off + p * vb.count + lane] = v0;
             }
         }
         __syncthreads();
@@ -155,7 +181,7 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
         // ---- CN pass (decoder.cpp:25-45), entirely in registers ----
         // (a fold expression, not a loop: every m[k] must be a compile-time register row)
         [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
-            ((have[Ks] ? cn_regs<MINSUM, MAXD>(m[Ks], deg[Ks]) : void()), ...);
+            ((have[Ks] ? cn_regs<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks]) : void()), ...);
         }(std::make_integer_sequence<int, KC>{});
 
         int par[KC];
@@ -184,6 +210,35 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
                     const int rank = vb.first + lane;
                     double *col = mb + vb.mb_off + lane;
                     uint8_t *hcol = hbm + vb.mb_off + lane;
+                    if constexpr (RATIO)
+                        if (vb.degree > 0)
+                        {
+                            // lambda(total) = lambda(L_ch) * prod lambda(c2v_p), in column file order
+                            double prod = llr[rank];
+                            if (vb.degree <= 3)
+                                for (int p = 0; p < vb.degree; ++p)
+                                    prod *= col[p * vb.count];
+                            else
+                                for (int p = 0; p < vb.degree; ++p)
+                                {
+                                    prod *= col[p * vb.count];
+                                    if (p % 3 == 2)
+                                        escaped |= dm_ratio_out_of_range(prod);
+                                }
+                            const uint8_t bit = prod >= 1.0; // total LLR <= 0
+                            const double tot = 1.0 / prod;   // rho(total)
+                            for (int p = 0; p < vb.degree; ++p)
+                            {
+                                const double o = tot * col[p * vb.count]; // rho(total - c2v_p)
+                                escaped |= dm_ratio_out_of_range(o);
+                                col[p * vb.count] = o;
+                                hcol[p * vb.count] = bit;
+                            }
+                            hard[rank] = bit;
+                            if constexpr (WANT_LLR)
+                                out_llr[P.rank_col[rank]] = 0.0 - dm_log(prod);
+                            continue;
+                        }
                     double out = llr[rank];
                     for (int p = 0; p < vb.degree; ++p) // sequential sum in column file order
                         out += col[p * vb.count];
@@ -215,6 +270,13 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
             __syncthreads();
         }
         // ---- syndrome early termination (decoder.cpp:66-72, decoder.h:47-64) ----
+        if constexpr (RATIO)
+            if (__syncthreads_or(escaped)) // checked before the syndrome: an escaped frame's hard decisions mean nothing
+            {
+                if (tid == 0)
+                    a.redo_list[atomicAdd(a.redo_count, 1u)] = static_cast<uint32_t>(frame);
+                return;
+            }
         if (a.early_term)
         {
             int bad = 0;
@@ -266,11 +328,16 @@ template <int NT, int KC, int MAXD>
 int launch_reg(const DecodeArgs &a, const DevRegPlan &r, bool min_sum, void *stream)
 {
     const bool want_llr = a.llr_out != nullptr;
+    const bool ratio = a.redo_list != nullptr;
+    if (ratio && (min_sum || !a.early_term || a.iterations == 0 || !a.redo_count || a.redo_count_in))
+        return hipErrorInvalidValue;
     void (*k)(const DecodeArgs, const DevRegPlan) = nullptr;
     if (min_sum)
-        k = want_llr ? decode_reg_kernel<true, true, NT, KC, MAXD> : decode_reg_kernel<true, false, NT, KC, MAXD>;
+        k = want_llr ? decode_reg_kernel<true, true, NT, KC, MAXD, false> : decode_reg_kernel<true, false, NT, KC, MAXD, false>;
+    else if (ratio)
+        k = want_llr ? decode_reg_kernel<false, true, NT, KC, MAXD, true> : decode_reg_kernel<false, false, NT, KC, MAXD, true>;
     else
-        k = want_llr ? decode_reg_kernel<false, true, NT, KC, MAXD> : decode_reg_kernel<false, false, NT, KC, MAXD>;
+        k = want_llr ? decode_reg_kernel<false, true, NT, KC, MAXD, false> : decode_reg_kernel<false, false, NT, KC, MAXD, false>;
     const uint32_t lds = r.mb_doubles * 9u;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));

@@ -423,8 +423,140 @@ static int is_codeword(const dec_t *d)
     return 1;
 }
 
+/*
+ * ORC_MATH_DET only: the sum-product iteration in likelihood-ratio form (detmath.h, "Likelihood-ratio form") —
+ * the arithmetic the HIP kernels run for BP with early termination.  v2c[] holds rho = e^L, c2v[] holds
+ * lambda = e^-L.  Same schedule, same orders of accumulation as decoder.cpp:11-78.  Returns -1 when a value
+ * of the frame leaves the representable box; the caller then decodes the frame with the LLR-domain form.
+ */
+static void cn_update_ratio(dec_t *d, const int *cn, int cw)
+{
+    enum { MAXD = 64 };
+    double v[MAXD], F[MAXD], B[MAXD];
+    for (int j = 0; j < cw; ++j)
+        v[j] = d->v2c[cn[j]];
+    if (cw == 2)
+    {
+        d->c2v[cn[0]] = 1.0 / v[1];
+        d->c2v[cn[1]] = 1.0 / v[0];
+    }
+    else if (cw == 3)
+    {
+        d->c2v[cn[0]] = dm_ratio_lambda(v[2], v[1]);
+        d->c2v[cn[1]] = dm_ratio_lambda(v[0], v[2]);
+        d->c2v[cn[2]] = dm_ratio_lambda(v[0], v[1]);
+    }
+    else if (cw == 4)
+    {
+        double nF = DM_FMA(v[0], v[1], 1.0), dF = v[0] + v[1];
+        double nB = DM_FMA(v[3], v[2], 1.0), dB = v[3] + v[2];
+        d->c2v[cn[0]] = dm_ratio_lambda_frac(nB, dB, v[1]);
+        d->c2v[cn[1]] = dm_ratio_lambda_frac(nB, dB, v[0]);
+        d->c2v[cn[2]] = dm_ratio_lambda_frac(nF, dF, v[3]);
+        d->c2v[cn[3]] = dm_ratio_lambda_frac(nF, dF, v[2]);
+    }
+    else
+    {
+        F[0] = v[0];
+        B[cw - 1] = v[cw - 1];
+        for (int j = 1; j <= cw - 3; ++j)
+            F[j] = dm_ratio_rho(F[j - 1], v[j]);
+        for (int j = cw - 2; j >= 2; --j)
+            B[j] = dm_ratio_rho(B[j + 1], v[j]);
+        d->c2v[cn[0]] = dm_ratio_lambda(B[2], v[1]);
+        d->c2v[cn[cw - 1]] = dm_ratio_lambda(F[cw - 3], v[cw - 2]);
+        for (int j = 1; j < cw - 1; ++j)
+            d->c2v[cn[j]] = dm_ratio_lambda(F[j - 1], B[j + 1]);
+    }
+}
+
+static int dec_decode_ratio(dec_t *d)
+{
+    const spm *H = &d->code->H;
+    double *lam = malloc(8 * (size_t)(H->cols > 0 ? H->cols : 1));
+    int escaped = 0;
+    for (int i = 0; i < H->cols; ++i)
+    {
+        if (H->cptr[i + 1] == H->cptr[i])
+            continue; /* isolated variable node: its LLR multiplies nothing */
+        double L = d->llr_in[i];
+        escaped |= !(fabs(L) <= DM_RATIO_LLR_LIMIT);
+        lam[i] = dm_exp(0.0 - L);
+        double v0 = 1.0 / lam[i];
+        for (int p = H->cptr[i]; p < H->cptr[i + 1]; ++p)
+            d->v2c[H->cedge[p]] = v0;
+    }
+    unsigned I = 0;
+    int ret = -1;
+    while (I < d->iterations)
+    {
+        for (int i = 0; i < H->rows; ++i)
+        {
+            int cw = H->rptr[i + 1] - H->rptr[i];
+            if (cw > 64)
+            {
+                escaped = 1;
+                break;
+            }
+            cn_update_ratio(d, H->redge + H->rptr[i], cw);
+        }
+        for (int i = 0; i < H->cols && !escaped; ++i)
+        {
+            int deg = H->cptr[i + 1] - H->cptr[i];
+            if (deg == 0)
+            {
+                d->llr_out[i] = d->llr_in[i];
+                d->co[i] = (uint8_t)(d->llr_in[i] <= 0);
+                continue;
+            }
+            double prod = lam[i];
+            for (int k = 0; k < deg; ++k)
+            {
+                prod *= d->c2v[H->cedge[H->cptr[i] + k]];
+                if (deg > 3 && k % 3 == 2)
+                    escaped |= dm_ratio_out_of_range(prod);
+            }
+            d->co[i] = (uint8_t)(prod >= 1.0);
+            d->llr_out[i] = 0.0 - dm_log(prod);
+            double tot = 1.0 / prod;
+            for (int k = 0; k < deg; ++k)
+            {
+                int e = H->cedge[H->cptr[i] + k];
+                double o = tot * d->c2v[e];
+                escaped |= dm_ratio_out_of_range(o);
+                d->v2c[e] = o;
+            }
+        }
+        if (escaped)
+            break;
+        if (is_codeword(d))
+        {
+            ret = (int)I;
+            break;
+        }
+        ++I;
+        if (I == d->iterations)
+            ret = (int)I;
+    }
+    free(lam);
+    return ret;
+}
+
+static int dec_decode_llr(dec_t *d);
+
 /* decoder.cpp:11-78 */
 static int dec_decode(dec_t *d)
+{
+    if (d->cn == jacobian_det && d->early_term && d->iterations > 0)
+    {
+        int it = dec_decode_ratio(d);
+        if (it >= 0)
+            return it;
+    }
+    return dec_decode_llr(d);
+}
+
+static int dec_decode_llr(dec_t *d)
 {
     const spm *H = &d->code->H;
     for (int e = 0; e < H->nnz; ++e)

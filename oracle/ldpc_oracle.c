@@ -432,7 +432,7 @@ static int is_codeword(const dec_t *d)
 static void cn_update_ratio(dec_t *d, const int *cn, int cw)
 {
     enum { MAXD = 64 };
-    double v[MAXD], F[MAXD], B[MAXD];
+    double v[MAXD] = {0}, F[MAXD], B[MAXD];
     for (int j = 0; j < cw; ++j)
         v[j] = d->v2c[cn[j]];
     if (cw == 2)
@@ -493,7 +493,7 @@ static int dec_decode_ratio(dec_t *d)
         for (int i = 0; i < H->rows; ++i)
         {
             int cw = H->rptr[i + 1] - H->rptr[i];
-            if (cw > 64)
+            if (cw > 64 || cw < 2)
             {
                 escaped = 1;
                 break;
@@ -544,6 +544,18 @@ static int dec_decode_ratio(dec_t *d)
 
 static int dec_decode_llr(dec_t *d);
 
+/* test introspection: frames the ratio form finished / handed back since the last reset (not thread-safe) */
+static uint64_t g_ratio_done, g_ratio_escaped;
+void orc_ratio_stats(uint64_t *done, uint64_t *escaped, int reset)
+{
+    if (done)
+        *done = g_ratio_done;
+    if (escaped)
+        *escaped = g_ratio_escaped;
+    if (reset)
+        g_ratio_done = g_ratio_escaped = 0;
+}
+
 /* decoder.cpp:11-78 */
 static int dec_decode(dec_t *d)
 {
@@ -551,7 +563,11 @@ static int dec_decode(dec_t *d)
     {
         int it = dec_decode_ratio(d);
         if (it >= 0)
+        {
+            ++g_ratio_done;
             return it;
+        }
+        ++g_ratio_escaped;
     }
     return dec_decode_llr(d);
 }

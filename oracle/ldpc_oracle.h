@@ -65,6 +65,10 @@ int orc_decode(const orc_code *c, int min_sum, int early_term, unsigned iteratio
 int orc_decode_bec(const orc_code *c, int early_term, unsigned iterations, int deg1_compat,
                    const uint8_t *llr_in, const uint8_t *codeword, uint8_t *llr_out, uint8_t *hard);
 
+/* ORC_MATH_DET, sum-product with early termination: frames finished by the likelihood-ratio form / handed back
+   to the LLR-domain form since the last reset (test introspection; single-threaded use only) */
+void orc_ratio_stats(uint64_t *done, uint64_t *escaped, int reset);
+
 /* ---- channel + decoder object: channel.cpp (one per reference OpenMP thread) ---- */
 orc_chan *orc_chan_new(const orc_code *c, int chan_type, uint64_t seed, int math_mode,
                        int min_sum, int early_term, unsigned iterations, int bec_deg1_compat);

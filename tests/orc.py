@@ -62,6 +62,7 @@ def lib():
     L.orc_simulate.restype = i32
     L.orc_simulate.argtypes = [vp, i32, u64, vp, i32, i32, u32, i32, i32, u32, u64, u64, vp, vp, vp]
     L.orc_mt64_stream.argtypes = [u64, u64, vp]
+    L.orc_ratio_stats.argtypes = [vp, vp, i32]
     L.orc_exp.restype, L.orc_exp.argtypes = dbl, [i32, dbl]
     L.orc_log.restype, L.orc_log.argtypes = dbl, [i32, dbl]
     _lib = L
@@ -175,6 +176,13 @@ def shortened_variant(path):
     assert "shorten [0]: " in txt
     open(path, "w").write(txt.replace("shorten [0]: ", "shorten [4]: 130 290 0 1"))
     return path
+
+
+def ratio_stats(reset=False):
+    """(frames finished by the likelihood-ratio form, frames handed back to the LLR-domain form) since reset."""
+    done, esc = ct.c_uint64(0), ct.c_uint64(0)
+    lib().orc_ratio_stats(ct.byref(done), ct.byref(esc), int(reset))
+    return done.value, esc.value
 
 
 def mt64_stream(seed, n):

@@ -147,6 +147,19 @@ def test_8k_bit_exact_vs_det_oracle(dec8k, h8k_file):
             assert np.array_equal(r[k], o[k].astype(r[k].dtype)), (ch, x, k)
 
 
+def test_8k_ratio_form_escapes(dec8k, h8k_file):
+    """Register-resident kernel: at 13.5 dB some frames leave the likelihood-ratio box and are re-decoded."""
+    code = orc.Code(h8k_file)
+    orc.ratio_stats(reset=True)
+    o = code.run_frames("AWGN", 13.5, seed=3, count=8, math=orc.MATH_DET)
+    done, escaped = orc.ratio_stats()
+    assert 0 < escaped < 8 and done + escaped == 8
+    dec8k.stream_begin("AWGN", 3, 13.5)
+    r = dec8k.stream_decode(8, want=OUT)
+    for k in OUT:
+        assert np.array_equal(r[k], o[k].astype(r[k].dtype)), k
+
+
 def test_8k_counters_vs_reference(dec8k, golden_8k):
     dec8k.stream_begin("AWGN", 0, 1.3)
     r = dec8k.stream_decode(60)

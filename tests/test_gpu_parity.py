@@ -104,6 +104,28 @@ def test_awgn_stream_bit_exact_vs_det_oracle(dec, ocode):
         assert dec.stream_raw_draws == o["raw_draws"]
 
 
+def test_ratio_form_hands_back_escaped_frames(dec, ocode):
+    """Sum-product with early termination runs in likelihood-ratio form; a frame whose values leave the box that
+    form can represent is decoded again by the LLR-domain form.  At these points some frames of the
+    batch take each route (checked on the oracle, which applies the same per-frame rule): still bit-exact."""
+    mixed = 0
+    for x, seed, count in [(6.0, 3, 64), (10.0, 3, 64), (12.0, 5, 64)]:
+        orc.ratio_stats(reset=True)
+        o = ocode.run_frames("AWGN", x, seed=seed, count=count, math=orc.MATH_DET)
+        done, escaped = orc.ratio_stats()
+        assert done + escaped == count
+        mixed += 0 < escaped < count
+        r = _stream(dec, "AWGN", x, seed, 0, count, decoding="BP")
+        for k in ("llr_in", "iters", "bit_errors", "hard", "llr_out"):
+            assert np.array_equal(r[k], o[k]), (x, seed, k)
+        # and without the LLR outputs (the instantiation the simulation loop uses)
+        dec.stream_begin("AWGN", seed, x)
+        r2 = dec.stream_decode(count, want=("iters", "bit_errors", "hard"), decoding="BP")
+        for k in ("iters", "bit_errors", "hard"):
+            assert np.array_equal(r2[k], o[k]), (x, seed, k)
+    assert mixed >= 2
+
+
 def test_awgn_stream_vs_reference(dec, golden_frames):
     for name, x, seed, skip, ms in [("awgn_bp_m4", -4.0, 0, 0, False), ("awgn_ms_m5", -5.0, 0, 0, True),
                                     ("awgn_bp_m4_skip1216", -4.0, 0, 1216, False)]:

@@ -57,7 +57,8 @@ def test_random_code_bit_exact(case, tmp_path):
         assert d.residency == residency, d.residency
     # channel points chosen so that some frames converge and some do not
     for ch, x, ms, early, iters in (("AWGN", 3.0, False, True, 20), ("AWGN", 1.0, True, True, 15),
-                                    ("AWGN", 2.0, False, False, 4), ("BSC", 0.03, False, True, 20),
+                                    ("AWGN", 2.0, False, False, 4), ("AWGN", 9.0, False, True, 20),
+                                    ("AWGN", 13.0, False, True, 20), ("BSC", 0.03, False, True, 20),
                                     ("BEC", 0.25, False, True, 20)):
         if ch == "BEC" and d.residency != "lds" and d.nnz > 100000:
             continue

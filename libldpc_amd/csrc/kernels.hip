@@ -33,23 +33,20 @@ constexpr int kThreads = kDecodeWaves * kWaveSize;
 constexpr uint8_t kErasure = 'E'; // functions.h:105
 
 // check-node update on the frame's message array: slot(j) = m[j*stride] (decoder.cpp:25-45, device_cn.hpp)
-template <int D, bool MINSUM, bool RATIO>
+template <int D, bool MINSUM>
 __device__ __forceinline__ void cn_update(double *m, int stride)
 {
     double v[D];
 #pragma unroll
     for (int j = 0; j < D; ++j)
         v[j] = m[j * stride];
-    if constexpr (RATIO)
-        cn_ratio<D>(v);
-    else
-        cn_core<D, MINSUM>(v);
+    cn_core<D, MINSUM>(v);
 #pragma unroll
     for (int j = 0; j < D; ++j)
         m[j * stride] = v[j];
 }
 
-template <bool MINSUM, int MAXD, bool RATIO>
+template <bool MINSUM, int MAXD>
 __device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane)
 {
     if (lane >= b.count)
@@ -58,18 +55,18 @@ __device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane)
     const int s = b.count;
     switch (b.degree) // wave-uniform
     {
-    case 2: cn_update<2, MINSUM, RATIO>(m, s); break;
-    case 3: cn_update<3, MINSUM, RATIO>(m, s); break;
-    case 4: cn_update<4, MINSUM, RATIO>(m, s); break;
+    case 2: cn_update<2, MINSUM>(m, s); break;
+    case 3: cn_update<3, MINSUM>(m, s); break;
+    case 4: cn_update<4, MINSUM>(m, s); break;
     default:
         if constexpr (MAXD > 4)
         {
             switch (b.degree)
             {
-            case 5: cn_update<5, MINSUM, RATIO>(m, s); break;
-            case 6: cn_update<6, MINSUM, RATIO>(m, s); break;
-            case 7: cn_update<7, MINSUM, RATIO>(m, s); break;
-            case 8: cn_update<8, MINSUM, RATIO>(m, s); break;
+            case 5: cn_update<5, MINSUM>(m, s); break;
+            case 6: cn_update<6, MINSUM>(m, s); break;
+            case 7: cn_update<7, MINSUM>(m, s); break;
+            case 8: cn_update<8, MINSUM>(m, s); break;
             default: break;
             }
         }
@@ -77,19 +74,154 @@ __device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane)
         {
             switch (b.degree)
             {
-            case 9: cn_update<9, MINSUM, RATIO>(m, s); break;
-            case 10: cn_update<10, MINSUM, RATIO>(m, s); break;
-            case 11: cn_update<11, MINSUM, RATIO>(m, s); break;
-            case 12: cn_update<12, MINSUM, RATIO>(m, s); break;
-            case 13: cn_update<13, MINSUM, RATIO>(m, s); break;
-            case 14: cn_update<14, MINSUM, RATIO>(m, s); break;
-            case 15: cn_update<15, MINSUM, RATIO>(m, s); break;
-            case 16: cn_update<16, MINSUM, RATIO>(m, s); break;
+            case 9: cn_update<9, MINSUM>(m, s); break;
+            case 10: cn_update<10, MINSUM>(m, s); break;
+            case 11: cn_update<11, MINSUM>(m, s); break;
+            case 12: cn_update<12, MINSUM>(m, s); break;
+            case 13: cn_update<13, MINSUM>(m, s); break;
+            case 14: cn_update<14, MINSUM>(m, s); break;
+            case 15: cn_update<15, MINSUM>(m, s); break;
+            case 16: cn_update<16, MINSUM>(m, s); break;
             default: break;
             }
         }
         break;
     }
+}
+
+// ---- likelihood-ratio form (RATIO instantiations): all messages are positive, so the sign bit of a message slot
+// is free and carries the hard decision of the edge's variable node (set by the VN pass, preserved by the CN
+// pass).  The CN pass therefore sees the syndrome of the previous iteration for free. ----
+__device__ __forceinline__ uint32_t hi_word(double x) { return static_cast<uint32_t>(dm_bits(x) >> 32); }
+__device__ __forceinline__ double with_sign(double mag, uint32_t sign_hi) // mag > 0, sign_hi = 0 or 0x80000000
+{
+    return dm_from_bits(dm_bits(mag) | (static_cast<uint64_t>(sign_hi) << 32));
+}
+
+template <int D>
+__device__ __forceinline__ uint32_t cn_update_ratio(double *m, int stride)
+{
+    double v[D];
+    uint32_t sg[D], par = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+    {
+        const double x = m[j * stride];
+        sg[j] = hi_word(x) & 0x80000000u;
+        par ^= sg[j];
+        v[j] = __builtin_fabs(x);
+    }
+    cn_ratio<D>(v);
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        m[j * stride] = with_sign(v[j], sg[j]);
+    return par;
+}
+
+// returns the parity (bit 31) of the hard decisions on this lane's check node
+template <int MAXD>
+__device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b, int lane)
+{
+    if (lane >= b.count)
+        return 0;
+    double *m = msg + b.off + lane;
+    const int s = b.count;
+    switch (b.degree) // wave-uniform
+    {
+    case 2: return cn_update_ratio<2>(m, s);
+    case 3: return cn_update_ratio<3>(m, s);
+    case 4: return cn_update_ratio<4>(m, s);
+    default: break;
+    }
+    if constexpr (MAXD > 4)
+        switch (b.degree)
+        {
+        case 5: return cn_update_ratio<5>(m, s);
+        case 6: return cn_update_ratio<6>(m, s);
+        case 7: return cn_update_ratio<7>(m, s);
+        case 8: return cn_update_ratio<8>(m, s);
+        default: break;
+        }
+    if constexpr (MAXD > 8)
+        switch (b.degree)
+        {
+        case 9: return cn_update_ratio<9>(m, s);
+        case 10: return cn_update_ratio<10>(m, s);
+        case 11: return cn_update_ratio<11>(m, s);
+        case 12: return cn_update_ratio<12>(m, s);
+        case 13: return cn_update_ratio<13>(m, s);
+        case 14: return cn_update_ratio<14>(m, s);
+        case 15: return cn_update_ratio<15>(m, s);
+        case 16: return cn_update_ratio<16>(m, s);
+        default: break;
+        }
+    return 0;
+}
+
+// VN update of one node in likelihood-ratio form, fully unrolled for degree DV (all loads in flight at once):
+// lambda(total) = lam * prod_p lambda(c2v_p) in column file order; v2c_p = lambda(c2v_p) / lambda(total).
+// Returns lambda(total); the hard decision (total LLR <= 0) goes into the sign bit of every v2c written.
+template <int DV>
+__device__ __forceinline__ double vn_update_ratio(double *msg, const uint32_t *idx, int count, double lam, int &escaped)
+{
+    uint32_t s[DV];
+    double c[DV];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        s[p] = idx[p * count];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        c[p] = __builtin_fabs(msg[s[p]]);
+    double prod = lam;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+    {
+        prod *= c[p];
+        if (DV > 3 && p % 3 == 2)
+            escaped |= dm_ratio_out_of_range(prod);
+    }
+    const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u; // total LLR <= 0: hard decision 1
+    const double tot = 1.0 / prod;                        // rho(total)
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+    {
+        const double o = tot * c[p]; // rho(total - c2v_p)
+        escaped |= dm_ratio_out_of_range(o);
+        msg[s[p]] = with_sign(o, sign);
+    }
+    return prod;
+}
+
+__device__ __forceinline__ double vn_block_ratio(double *msg, const uint32_t *idx, int count, int degree, double lam,
+                                                 int &escaped)
+{
+    switch (degree) // wave-uniform
+    {
+#define LDPC_VN(D) \
+    case D: return vn_update_ratio<D>(msg, idx, count, lam, escaped);
+        LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
+        LDPC_VN(9) LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15) LDPC_VN(16)
+#undef LDPC_VN
+    default: break;
+    }
+    // any other degree: the same arithmetic with run-time loops
+    double prod = lam;
+    for (int p = 0; p < degree; ++p)
+    {
+        prod *= __builtin_fabs(msg[idx[p * count]]);
+        if (p % 3 == 2)
+            escaped |= dm_ratio_out_of_range(prod);
+    }
+    const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u;
+    const double tot = 1.0 / prod;
+    for (int p = 0; p < degree; ++p)
+    {
+        const uint32_t sl = idx[p * count];
+        const double o = tot * __builtin_fabs(msg[sl]);
+        escaped |= dm_ratio_out_of_range(o);
+        msg[sl] = with_sign(o, sign);
+    }
+    return prod;
 }
 
 __device__ __forceinline__ int wave_sum(int v)
@@ -263,88 +395,24 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 
     double *out_llr = WANT_LLR ? a.llr_out + frame * nc : nullptr;
     uint32_t I = 0;
-    while (I < a.iterations)
+    if constexpr (RATIO)
     {
-        // ---- CN pass: decoder.cpp:25-45 ----
-        for (int w = 0; w < P.cn_work_stride; ++w)
+        // Likelihood-ratio form.  Loop I: the CN pass of iteration I, which also reads — from the sign bits of the
+        // v2c messages — the syndrome of the hard decisions made by VN pass I-1; one barrier with the vote; then
+        // VN pass I.  A frame that converged after VN pass I-1 (or ran out of iterations) has made one CN pass
+        // too many, which nothing reads: two barriers per iteration instead of three, no hard-bit array.
+        for (;;)
         {
-            const uint32_t bi = my_cn[w];
-            if (bi == 0xFFFF)
-                break;
-            cn_block<MINSUM, MAXD, RATIO>(msg, load_block2(P.cn_blocks, bi), lane);
-        }
-        __syncthreads();
-
-        // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
-        for_my_vn_blocks([&](const VnBlock &b, double L) {
-            const uint32_t *idx = P.vn_slot + b.idx_off + lane;
-            if constexpr (RATIO)
-            {
-                // lambda(total) = lambda(L_ch) * prod lambda(c2v_p), in column file order
-                double prod = L;
-                if (b.degree <= 3)
-                    for (int p = 0; p < b.degree; ++p)
-                        prod *= msg[idx[p * b.count]];
-                else
-                    for (int p = 0; p < b.degree; ++p)
-                    {
-                        prod *= msg[idx[p * b.count]];
-                        if (p % 3 == 2)
-                            escaped |= dm_ratio_out_of_range(prod);
-                    }
-                const uint8_t bit = prod >= 1.0; // total LLR <= 0
-                const double tot = 1.0 / prod;   // rho(total)
-                for (int p = 0; p < b.degree; ++p)
-                {
-                    const uint32_t s = idx[p * b.count];
-                    const double o = tot * msg[s]; // rho(total - c2v_p)
-                    escaped |= dm_ratio_out_of_range(o);
-                    msg[s] = o;
-                    hb[s] = bit;
-                }
-                if constexpr (WANT_LLR)
-                    out_llr[P.rank_col[b.first + lane]] = 0.0 - dm_log(prod);
-                return;
-            }
-            double out = L;
-            for (int p = 0; p < b.degree; ++p) // sequential sum in column file order
-                out += msg[idx[p * b.count]];
-            const uint8_t bit = out <= 0;
-            for (int p = 0; p < b.degree; ++p)
-            {
-                const uint32_t s = idx[p * b.count];
-                msg[s] = out - msg[s];
-                hb[s] = bit;
-            }
-            if constexpr (WANT_LLR)
-                out_llr[P.rank_col[b.first + lane]] = out;
-        });
-        __syncthreads();
-
-        // ---- syndrome early termination: decoder.cpp:66-72, decoder.h:47-64 ----
-        if (a.early_term)
-        {
-            int bad = 0;
+            uint32_t bad = 0;
             for (int w = 0; w < P.cn_work_stride; ++w)
             {
                 const uint32_t bi = my_cn[w];
                 if (bi == 0xFFFF)
                     break;
-                const CnBlock b = load_block2(P.cn_blocks, bi);
-                if (lane < b.count)
-                {
-                    int par = 0;
-                    for (int j = 0; j < b.degree; ++j)
-                        par ^= hb[b.off + j * b.count + lane];
-                    bad |= par;
-                }
+                bad |= cn_block_ratio<MAXD>(msg, load_block2(P.cn_blocks, bi), lane);
             }
-            // workgroup-wide OR with one barrier: every wave posts its vote in a slot of the iteration's parity
-            // (slots alternate, so the next iteration's votes cannot overtake a slow reader)
             const int ph = I & 1;
-            int wave_vote = __ballot(bad != 0) != 0;
-            if constexpr (RATIO)
-                wave_vote |= (__ballot(escaped != 0) != 0) << 1;
+            const int wave_vote = (__ballot(bad != 0) != 0) | ((__ballot(escaped != 0) != 0) << 1);
             if (lane == 0)
                 votes[ph][wave] = wave_vote;
             __syncthreads();
@@ -352,17 +420,97 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 #pragma unroll
             for (int w = 0; w < kDecodeWaves; ++w)
                 any |= votes[ph][w];
-            if constexpr (RATIO)
-                if (any & 2) // checked before the syndrome: an escaped frame's hard decisions mean nothing
-                {
-                    if (tid == 0)
-                        a.redo_list[atomicAdd(a.redo_count, 1u)] = static_cast<uint32_t>(frame);
-                    return;
-                }
-            if (!any)
+            if (any & 2) // checked before the syndrome: an escaped frame's hard decisions mean nothing
+            {
+                if (tid == 0)
+                    a.redo_list[atomicAdd(a.redo_count, 1u)] = static_cast<uint32_t>(frame);
+                return;
+            }
+            if (I > 0 && !(any & 1)) // decoder.cpp:66-72 after VN pass I-1
+            {
+                --I;
                 break;
+            }
+            if (I == a.iterations)
+                break;
+            // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
+            for_my_vn_blocks([&](const VnBlock &b, double lam) {
+                if (b.degree == 0)
+                    return;
+                const double prod = vn_block_ratio(msg, P.vn_slot + b.idx_off + lane, b.count, b.degree, lam, escaped);
+                if constexpr (WANT_LLR)
+                    out_llr[P.rank_col[b.first + lane]] = 0.0 - dm_log(prod);
+            });
+            __syncthreads();
+            ++I;
         }
-        ++I;
+    }
+    else
+    {
+        while (I < a.iterations)
+        {
+            // ---- CN pass: decoder.cpp:25-45 ----
+            for (int w = 0; w < P.cn_work_stride; ++w)
+            {
+                const uint32_t bi = my_cn[w];
+                if (bi == 0xFFFF)
+                    break;
+                cn_block<MINSUM, MAXD>(msg, load_block2(P.cn_blocks, bi), lane);
+            }
+            __syncthreads();
+
+            // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
+            for_my_vn_blocks([&](const VnBlock &b, double L) {
+                const uint32_t *idx = P.vn_slot + b.idx_off + lane;
+                double out = L;
+                for (int p = 0; p < b.degree; ++p) // sequential sum in column file order
+                    out += msg[idx[p * b.count]];
+                const uint8_t bit = out <= 0;
+                for (int p = 0; p < b.degree; ++p)
+                {
+                    const uint32_t s = idx[p * b.count];
+                    msg[s] = out - msg[s];
+                    hb[s] = bit;
+                }
+                if constexpr (WANT_LLR)
+                    out_llr[P.rank_col[b.first + lane]] = out;
+            });
+            __syncthreads();
+
+            // ---- syndrome early termination: decoder.cpp:66-72, decoder.h:47-64 ----
+            if (a.early_term)
+            {
+                int bad = 0;
+                for (int w = 0; w < P.cn_work_stride; ++w)
+                {
+                    const uint32_t bi = my_cn[w];
+                    if (bi == 0xFFFF)
+                        break;
+                    const CnBlock b = load_block2(P.cn_blocks, bi);
+                    if (lane < b.count)
+                    {
+                        int par = 0;
+                        for (int j = 0; j < b.degree; ++j)
+                            par ^= hb[b.off + j * b.count + lane];
+                        bad |= par;
+                    }
+                }
+                // workgroup-wide OR with one barrier: every wave posts its vote in a slot of the iteration's parity
+                // (slots alternate, so the next iteration's votes cannot overtake a slow reader)
+                const int ph = I & 1;
+                const int wave_vote = __ballot(bad != 0) != 0;
+                if (lane == 0)
+                    votes[ph][wave] = wave_vote;
+                __syncthreads();
+                int any = 0;
+    #pragma unroll
+                for (int w = 0; w < kDecodeWaves; ++w)
+                    any |= votes[ph][w];
+                if (!any)
+                    break;
+            }
+            ++I;
+        }
     }
 
     // ---- outputs: iteration count (decoder.cpp:74-77), hard decisions, bit errors (ldpcsim.cpp:184-188) ----
@@ -373,10 +521,16 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
         if (!ran)
             return 0; // mCO is still zero-initialised when no iteration ran
         uint32_t s0 = P.rank_slot0[r];
+        auto edge_bit = [&](uint32_t sl) -> int {
+            if constexpr (RATIO)
+                return hi_word(msg[sl]) >> 31; // the decision rides in the sign bit of the node's messages
+            else
+                return hb[sl];
+        };
         if constexpr (LLR_MODE == kLlrRegs)
-            return hb[s0]; // this mode is only used for codes without isolated variable nodes
+            return edge_bit(s0); // this mode is only used for codes without isolated variable nodes
         else
-            return s0 != kNoSlot ? hb[s0] : static_cast<int>(llr[r] <= 0);
+            return s0 != kNoSlot ? edge_bit(s0) : static_cast<int>(llr[r] <= 0);
     };
     if (a.hard)
     {

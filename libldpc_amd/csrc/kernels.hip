@@ -224,6 +224,57 @@ __device__ __forceinline__ double vn_block_ratio(double *msg, const uint32_t *id
     return prod;
 }
 
+// VN update of one node in the LLR domain (decoder.cpp:48-64), unrolled for degree DV: every message is read once.
+// Returns the APP LLR; v2c_p = APP - c2v_p, the hard decision goes to the hard-bit array.
+template <int DV>
+__device__ __forceinline__ double vn_update_llr(double *msg, uint8_t *hb, const uint32_t *idx, int count, double L)
+{
+    uint32_t s[DV];
+    double c[DV];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        s[p] = idx[p * count];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        c[p] = msg[s[p]];
+    double out = L;
+#pragma unroll
+    for (int p = 0; p < DV; ++p) // sequential sum in column file order
+        out += c[p];
+    const uint8_t bit = out <= 0;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+    {
+        msg[s[p]] = out - c[p];
+        hb[s[p]] = bit;
+    }
+    return out;
+}
+
+__device__ __forceinline__ double vn_block_llr(double *msg, uint8_t *hb, const uint32_t *idx, int count, int degree, double L)
+{
+    switch (degree) // wave-uniform
+    {
+#define LDPC_VN(D) \
+    case D: return vn_update_llr<D>(msg, hb, idx, count, L);
+        LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
+        LDPC_VN(9) LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15) LDPC_VN(16)
+#undef LDPC_VN
+    default: break;
+    }
+    double out = L;
+    for (int p = 0; p < degree; ++p)
+        out += msg[idx[p * count]];
+    const uint8_t bit = out <= 0;
+    for (int p = 0; p < degree; ++p)
+    {
+        const uint32_t sl = idx[p * count];
+        msg[sl] = out - msg[sl];
+        hb[sl] = bit;
+    }
+    return out;
+}
+
 __device__ __forceinline__ int wave_sum(int v)
 {
 #pragma unroll
@@ -461,17 +512,7 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 
             // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
             for_my_vn_blocks([&](const VnBlock &b, double L) {
-                const uint32_t *idx = P.vn_slot + b.idx_off + lane;
-                double out = L;
-                for (int p = 0; p < b.degree; ++p) // sequential sum in column file order
-                    out += msg[idx[p * b.count]];
-                const uint8_t bit = out <= 0;
-                for (int p = 0; p < b.degree; ++p)
-                {
-                    const uint32_t s = idx[p * b.count];
-                    msg[s] = out - msg[s];
-                    hb[s] = bit;
-                }
+                const double out = vn_block_llr(msg, hb, P.vn_slot + b.idx_off + lane, b.count, b.degree, L);
                 if constexpr (WANT_LLR)
                     out_llr[P.rank_col[b.first + lane]] = out;
             });

@@ -12,8 +12,11 @@
  * oracle/_ref/ (see oracle/ref_driver.cpp, tests/golden/make_golden.py and the committed
  * fixtures under tests/golden/).  With ORC_MATH_LIBM it is bit-identical to the reference
  * on this toolchain (glibc 2.35 libm, libstdc++ 11 <random> semantics restated below).
- * With ORC_MATH_DET, exp/log come from libldpc_amd/csrc/detmath.h — the same routines the
- * HIP kernels use — which makes GPU-vs-oracle comparisons bit-exact on every frame.
+ * With ORC_MATH_DET the transcendental arithmetic is that of libldpc_amd/csrc/detmath.h — the same routines
+ * and the same algebraic forms the HIP kernels use (deterministic exp/log; the check node in E = e^-|L|; for
+ * sum-product with early termination the whole iteration in likelihood-ratio form, with the per-frame
+ * fall-back rule described there) — which makes GPU-vs-oracle comparisons bit-exact on every frame.  Schedule,
+ * recursion order and summation order are the reference's in both modes.
  */
 #ifndef LDPC_ORACLE_H
 #define LDPC_ORACLE_H

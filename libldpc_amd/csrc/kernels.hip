@@ -18,6 +18,8 @@
 //   bit-error count        src/sim/ldpcsim.cpp:184-188
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "device_channel.hpp"
 #include "device_cn.hpp"
 #include "device_math.hpp"
@@ -118,6 +120,65 @@ __device__ __forceinline__ uint32_t cn_update_ratio(double *m, int stride)
     return par;
 }
 
+template <int MAXD>
+__device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b, int lane);
+template <int MAXD>
+__device__ __forceinline__ uint32_t cn_block_ratio_fwd(double *msg, const CnBlock b, int lane)
+{
+    return cn_block_ratio<MAXD>(msg, b, lane);
+}
+
+// two full blocks (64 nodes each) of the same degree at once: two independent chains per lane hide the latency of
+// the divisions and of the LDS round trip; the constant stride lets the loads pair up (ds_read2st64_b64)
+template <int D>
+__device__ __forceinline__ uint32_t cn_update_ratio2(double *m0, double *m1)
+{
+    double v0[D], v1[D];
+    uint32_t g0[D], g1[D], par0 = 0, par1 = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+    {
+        const double x0 = m0[j * kWaveSize], x1 = m1[j * kWaveSize];
+        g0[j] = hi_word(x0) & 0x80000000u, g1[j] = hi_word(x1) & 0x80000000u;
+        par0 ^= g0[j], par1 ^= g1[j];
+        v0[j] = __builtin_fabs(x0), v1[j] = __builtin_fabs(x1);
+    }
+    cn_ratio<D>(v0);
+    cn_ratio<D>(v1);
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+    {
+        m0[j * kWaveSize] = with_sign(v0[j], g0[j]);
+        m1[j * kWaveSize] = with_sign(v1[j], g1[j]);
+    }
+    return par0 | par1;
+}
+
+template <int MAXD>
+__device__ __forceinline__ uint32_t cn_pair_ratio(double *msg, uint32_t off0, uint32_t off1, int degree, int lane)
+{
+    double *m0 = msg + off0 + lane, *m1 = msg + off1 + lane;
+    switch (degree) // wave-uniform
+    {
+    case 2: return cn_update_ratio2<2>(m0, m1);
+    case 3: return cn_update_ratio2<3>(m0, m1);
+    case 4: return cn_update_ratio2<4>(m0, m1);
+    default: break;
+    }
+    if constexpr (MAXD > 4)
+        switch (degree)
+        {
+        case 5: return cn_update_ratio2<5>(m0, m1);
+        case 6: return cn_update_ratio2<6>(m0, m1);
+        case 7: return cn_update_ratio2<7>(m0, m1);
+        case 8: return cn_update_ratio2<8>(m0, m1);
+        default: break;
+        }
+    // wider nodes: one after the other
+    return cn_block_ratio_fwd<MAXD>(msg, CnBlock{off0, kWaveSize, static_cast<uint16_t>(degree)}, lane) |
+           cn_block_ratio_fwd<MAXD>(msg, CnBlock{off1, kWaveSize, static_cast<uint16_t>(degree)}, lane);
+}
+
 // returns the parity (bit 31) of the hard decisions on this lane's check node
 template <int MAXD>
 __device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b, int lane)
@@ -192,6 +253,149 @@ __device__ __forceinline__ double vn_update_ratio(double *msg, const uint32_t *i
     return prod;
 }
 
+// the same update for nodes of degree DV <= 2 whose slot indices the lane keeps in a register (two u16, kLlrRegs),
+// one node or two independent nodes (of two blocks) in lock step: no table load in front of the LDS round trip,
+// two chains in flight
+template <int DV>
+__device__ __forceinline__ double vn_small_ratio(double *msg, uint32_t packed, double lam, int &escaped)
+{
+    static_assert(DV >= 1 && DV <= 2, "register-held slot indices");
+    const uint32_t sl[2] = {packed & 0xFFFFu, packed >> 16};
+    double c[DV];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        c[p] = __builtin_fabs(msg[sl[p]]);
+    double prod = lam;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        prod *= c[p];
+    const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u;
+    const double tot = 1.0 / prod;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+    {
+        const double o = tot * c[p];
+        escaped |= dm_ratio_out_of_range(o);
+        msg[sl[p]] = with_sign(o, sign);
+    }
+    return prod;
+}
+
+template <int DV>
+__device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, uint32_t packed_b, double la, double lb,
+                                                int &escaped, double &pa, double &pb)
+{
+    static_assert(DV >= 1 && DV <= 2, "register-held slot indices");
+    const uint32_t sa[2] = {packed_a & 0xFFFFu, packed_a >> 16}, sb[2] = {packed_b & 0xFFFFu, packed_b >> 16};
+    double ca[DV], cb[DV];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        ca[p] = __builtin_fabs(msg[sa[p]]), cb[p] = __builtin_fabs(msg[sb[p]]);
+    pa = la, pb = lb;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        pa *= ca[p], pb *= cb[p];
+    const uint32_t sga = pa >= 1.0 ? 0x80000000u : 0u, sgb = pb >= 1.0 ? 0x80000000u : 0u;
+    const double ta = 1.0 / pa, tb = 1.0 / pb;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+    {
+        const double oa = ta * ca[p], ob = tb * cb[p];
+        escaped |= dm_ratio_out_of_range(oa) | dm_ratio_out_of_range(ob);
+        msg[sa[p]] = with_sign(oa, sga);
+        msg[sb[p]] = with_sign(ob, sgb);
+    }
+}
+
+// A node of up to 16 edges whose slot indices the lane keeps in registers (16 x u16 in eight words, kLlrRegs: the
+// first — widest — VN block of every wave): no table load at all, every message read once.
+template <int DV>
+__device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32_t (&packed)[8], double lam, int &escaped)
+{
+    auto slot = [&](int p) { return (p & 1) ? packed[p >> 1] >> 16 : packed[p >> 1] & 0xFFFFu; };
+    double c[DV];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        c[p] = __builtin_fabs(msg[slot(p)]);
+    double prod = lam;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+    {
+        prod *= c[p];
+        if (DV > 3 && p % 3 == 2)
+            escaped |= dm_ratio_out_of_range(prod);
+    }
+    const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u;
+    const double tot = 1.0 / prod;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+    {
+        const double o = tot * c[p];
+        escaped |= dm_ratio_out_of_range(o);
+        msg[slot(p)] = with_sign(o, sign);
+    }
+    return prod;
+}
+
+__device__ __forceinline__ double vn_block_ratio_regs(double *msg, const uint32_t (&packed)[8], int degree, double lam,
+                                                      int &escaped)
+{
+    switch (degree) // wave-uniform, 1..16
+    {
+#define LDPC_VN(D) \
+    case D: return vn_update_ratio_regs<D>(msg, packed, lam, escaped);
+        LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
+        LDPC_VN(9) LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15) LDPC_VN(16)
+#undef LDPC_VN
+    default: return lam;
+    }
+}
+
+// pieces of the same update for wider nodes still, N messages at a time: pass 1 multiplies N factors into the
+// running product (range check at every third position of the node, as everywhere), pass 2 writes N messages
+template <int N>
+__device__ __forceinline__ void vn_ratio_pass1(const double *msg, const uint32_t *idx, int count, int p0, double &prod,
+                                               int &escaped)
+{
+    uint32_t s[N];
+    double c[N];
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+        s[p] = idx[(p0 + p) * count];
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+        c[p] = __builtin_fabs(msg[s[p]]);
+    const int ph = p0 % 3; // wave-uniform
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+    {
+        prod *= c[p];
+        if ((ph + p) % 3 == 2)
+            escaped |= dm_ratio_out_of_range(prod);
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void vn_ratio_pass2(double *msg, const uint32_t *idx, int count, int p0, double tot,
+                                               uint32_t sign, int &escaped)
+{
+    uint32_t s[N];
+    double c[N];
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+        s[p] = idx[(p0 + p) * count];
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+        c[p] = __builtin_fabs(msg[s[p]]);
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+    {
+        const double o = tot * c[p];
+        escaped |= dm_ratio_out_of_range(o);
+        msg[s[p]] = with_sign(o, sign);
+    }
+}
+
 __device__ __forceinline__ double vn_block_ratio(double *msg, const uint32_t *idx, int count, int degree, double lam,
                                                  int &escaped)
 {
@@ -200,26 +404,33 @@ __device__ __forceinline__ double vn_block_ratio(double *msg, const uint32_t *id
 #define LDPC_VN(D) \
     case D: return vn_update_ratio<D>(msg, idx, count, lam, escaped);
         LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
-        LDPC_VN(9) LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15) LDPC_VN(16)
 #undef LDPC_VN
     default: break;
     }
-    // any other degree: the same arithmetic with run-time loops
+    // wider nodes still: eight messages at a time, every message read twice (registers stay bounded)
     double prod = lam;
-    for (int p = 0; p < degree; ++p)
+    int p0 = 0;
+    for (; p0 + 8 <= degree; p0 += 8)
+        vn_ratio_pass1<8>(msg, idx, count, p0, prod, escaped);
+    switch (degree - p0)
     {
-        prod *= __builtin_fabs(msg[idx[p * count]]);
-        if (p % 3 == 2)
-            escaped |= dm_ratio_out_of_range(prod);
+#define LDPC_VN(R) \
+    case R: vn_ratio_pass1<R>(msg, idx, count, p0, prod, escaped); break;
+        LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7)
+#undef LDPC_VN
+    default: break;
     }
     const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u;
     const double tot = 1.0 / prod;
-    for (int p = 0; p < degree; ++p)
+    for (p0 = 0; p0 + 8 <= degree; p0 += 8)
+        vn_ratio_pass2<8>(msg, idx, count, p0, tot, sign, escaped);
+    switch (degree - p0)
     {
-        const uint32_t sl = idx[p * count];
-        const double o = tot * __builtin_fabs(msg[sl]);
-        escaped |= dm_ratio_out_of_range(o);
-        msg[sl] = with_sign(o, sign);
+#define LDPC_VN(R) \
+    case R: vn_ratio_pass2<R>(msg, idx, count, p0, tot, sign, escaped); break;
+        LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7)
+#undef LDPC_VN
+    default: break;
     }
     return prod;
 }
@@ -378,12 +589,18 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
         __syncthreads();
     }
     double my_llr[kMaxVnBlocksInRegs];
+    uint32_t my_idx[kMaxVnBlocksInRegs]; // RATIO: slot indices (two u16) of this lane's nodes of degree <= 2
+    uint32_t wide_idx[8];                // RATIO: slot indices (16 x u16) of this lane's node in the wave's first block
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        wide_idx[i] = 0;
     if constexpr (LLR_MODE == kLlrRegs)
     {
 #pragma unroll
         for (int w = 0; w < kMaxVnBlocksInRegs; ++w)
         {
             my_llr[w] = 0.0;
+            my_idx[w] = 0;
             if (w < P.vn_work_stride)
             {
                 const uint32_t bi = my_vn[w];
@@ -397,6 +614,16 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
                         {
                             escaped |= !(__builtin_fabs(my_llr[w]) <= DM_RATIO_LLR_LIMIT);
                             my_llr[w] = dm_exp(0.0 - my_llr[w]);
+                            const uint32_t *idx = P.vn_slot + b.idx_off + lane; // LDS-resident: every slot < 2^16
+                            if (b.degree >= 1 && b.degree <= 2)
+                                my_idx[w] = idx[0] | (idx[(b.degree - 1) * b.count] << 16);
+                            else if (w == 0 && b.degree <= 16)
+                            {
+#pragma unroll
+                                for (int q = 0; q < 16; ++q)
+                                    if (q < b.degree)
+                                        wide_idx[q >> 1] |= idx[q * b.count] << (16 * (q & 1));
+                            }
                         }
                     }
                 }
@@ -455,12 +682,23 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
         for (;;)
         {
             uint32_t bad = 0;
-            for (int w = 0; w < P.cn_work_stride; ++w)
-            {
-                const uint32_t bi = my_cn[w];
-                if (bi == 0xFFFF)
+            for (int w = 0; w < P.cn_work_stride; w += 2) // blocks two at a time where they match (plan.cpp deals
+            {                                             // each wave's blocks in degree order)
+                const uint32_t bi0 = my_cn[w];
+                if (bi0 == 0xFFFF)
                     break;
-                bad |= cn_block_ratio<MAXD>(msg, load_block2(P.cn_blocks, bi), lane);
+                const CnBlock b0 = load_block2(P.cn_blocks, bi0);
+                const uint32_t bi1 = w + 1 < P.cn_work_stride ? my_cn[w + 1] : 0xFFFFu;
+                if (bi1 == 0xFFFF)
+                {
+                    bad |= cn_block_ratio<MAXD>(msg, b0, lane);
+                    break;
+                }
+                const CnBlock b1 = load_block2(P.cn_blocks, bi1);
+                if (b0.degree == b1.degree && b0.count == kWaveSize && b1.count == kWaveSize)
+                    bad |= cn_pair_ratio<MAXD>(msg, b0.off, b1.off, b0.degree, lane);
+                else
+                    bad |= cn_block_ratio<MAXD>(msg, b0, lane) | cn_block_ratio<MAXD>(msg, b1, lane);
             }
             const int ph = I & 1;
             const int wave_vote = (__ballot(bad != 0) != 0) | ((__ballot(escaped != 0) != 0) << 1);
@@ -485,13 +723,70 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
             if (I == a.iterations)
                 break;
             // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
-            for_my_vn_blocks([&](const VnBlock &b, double lam) {
-                if (b.degree == 0)
-                    return;
-                const double prod = vn_block_ratio(msg, P.vn_slot + b.idx_off + lane, b.count, b.degree, lam, escaped);
-                if constexpr (WANT_LLR)
-                    out_llr[P.rank_col[b.first + lane]] = 0.0 - dm_log(prod);
-            });
+            if constexpr (LLR_MODE == kLlrRegs)
+            {
+                auto put_llr = [&](const VnBlock &b, double prod) {
+                    if constexpr (WANT_LLR)
+                        out_llr[P.rank_col[b.first + lane]] = 0.0 - dm_log(prod);
+                };
+                // one block: degree 1 or 2 from its register-held indices, the wave's first block likewise when it
+                // has up to 16 edges per node, anything else through the slot table
+                auto one = [&](const VnBlock &b, int w, uint32_t sl, double lam) {
+                    if (lane >= b.count || b.degree == 0)
+                        return;
+                    double prod;
+                    if (b.degree == 1)
+                        prod = vn_small_ratio<1>(msg, sl, lam, escaped);
+                    else if (b.degree == 2)
+                        prod = vn_small_ratio<2>(msg, sl, lam, escaped);
+                    else if (w == 0 && b.degree <= 16)
+                        prod = vn_block_ratio_regs(msg, wide_idx, b.degree, lam, escaped);
+                    else
+                        prod = vn_block_ratio(msg, P.vn_slot + b.idx_off + lane, b.count, b.degree, lam, escaped);
+                    put_llr(b, prod);
+                };
+#pragma unroll
+                for (int w = 0; w < kMaxVnBlocksInRegs; w += 2) // full low-degree blocks two at a time in lock step
+                {                                               // (plan.cpp deals each wave's blocks in degree order)
+                    if (w >= P.vn_work_stride)
+                        break;
+                    const uint32_t bi0 = my_vn[w];
+                    if (bi0 == 0xFFFF)
+                        break;
+                    const VnBlock b0 = load_block3(P.vn_blocks, bi0);
+                    const uint32_t bi1 = w + 1 < P.vn_work_stride ? my_vn[w + 1] : 0xFFFFu;
+                    if (bi1 == 0xFFFF)
+                    {
+                        one(b0, w, my_idx[w], my_llr[w]);
+                        break;
+                    }
+                    const VnBlock b1 = load_block3(P.vn_blocks, bi1);
+                    if (b0.degree == b1.degree && b0.degree >= 1 && b0.degree <= 2 && b0.count == kWaveSize &&
+                        b1.count == kWaveSize)
+                    {
+                        double pa, pb;
+                        if (b0.degree == 1)
+                            vn_small_ratio2<1>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], escaped, pa, pb);
+                        else
+                            vn_small_ratio2<2>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], escaped, pa, pb);
+                        put_llr(b0, pa);
+                        put_llr(b1, pb);
+                    }
+                    else
+                    {
+                        one(b0, w, my_idx[w], my_llr[w]);
+                        one(b1, w + 1, my_idx[w + 1], my_llr[w + 1]);
+                    }
+                }
+            }
+            else
+                for_my_vn_blocks([&](const VnBlock &b, double lam) {
+                    if (b.degree == 0)
+                        return;
+                    const double prod = vn_block_ratio(msg, P.vn_slot + b.idx_off + lane, b.count, b.degree, lam, escaped);
+                    if constexpr (WANT_LLR)
+                        out_llr[P.rank_col[b.first + lane]] = 0.0 - dm_log(prod);
+                });
             __syncthreads();
             ++I;
         }

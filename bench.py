@@ -208,7 +208,7 @@ def main():
             "fer": fec / frames, "ber": bec / (frames * NC), "avg_iter": it_sum / frames,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
-                         "traffic_source": traffic_src, "kernel": "decode_kernel<BP, LDS-resident>",
+                         "traffic_source": traffic_src, "kernel": "decode_kernel<BP, LDS-resident, likelihood-ratio form>" if early and args.decoding == "BP" else "decode_kernel<%s, LDS-resident>" % args.decoding,
                          "algorithmic_bytes_per_launch": eu_rank / K * bpe, "kernel_ms_avg": sum(kernel_ms) / len(kernel_ms),
                          "rng_ms_avg": sum(rng_ms) / len(rng_ms), "bytes_per_edge_update": bpe,
                          "note": "messages are LDS-resident: achieved = algorithmic fp64 bytes of the reference "

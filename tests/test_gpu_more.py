@@ -289,3 +289,64 @@ def test_pyldpc_style_simulate_thread(golden_sim):
     res = c.get_results()
     assert res["frames"][:2] == [26, 180] and res["fec"][:2] == [20, 3]
     assert abs(res["fer"][0] - 20 / 26) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+SHARD_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import libldpc_amd
+from libldpc_amd import shard
+dist.init_process_group("gloo")                      # two ranks share the one GPU of the test box
+rank, _, world = shard.rank_world()
+per_rank = 700
+lo, hi = shard.frame_range(rank, world, per_rank)
+d = libldpc_amd.HipDecoder(%r, device=0)
+d.stream_begin("AWGN", 0, -4.0)
+if lo:
+    d.stream_skip(lo)                                # RNG-only seek to this rank's first frame of the stream
+r = d.stream_decode(hi - lo, want=("iters", "bit_errors"))
+c = shard.counters_from_outputs(torch, torch.from_numpy(r["iters"].astype(np.int32)),
+                                torch.from_numpy(r["bit_errors"].astype(np.int32)), 50, True)
+c = shard.reduce_counters(c, dist)
+np.save(os.path.join(%r, "counters%%d.npy" %% rank), c.numpy())
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_count_what_one_rank_counts(dec, tmp_path):
+    """SURVEY §8e: frames keep their identity in the one RNG stream, so the counters two ranks reduce over their
+    contiguous frame ranges equal the counters of a single rank decoding all frames (here both ranks use cuda:0
+    and the reduce runs over gloo; on a node it is one rank per GPU over RCCL)."""
+    import sys
+    import torch
+    from libldpc_amd import shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER % (root, orc.H_TXT, str(tmp_path)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29621", str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    dec.stream_begin("AWGN", 0, -4.0)
+    r = dec.stream_decode(1400, want=("iters", "bit_errors"))
+    one = shard.counters_from_outputs(torch, torch.from_numpy(r["iters"].astype(np.int32)),
+                                      torch.from_numpy(r["bit_errors"].astype(np.int32)), 50, True).numpy()
+    for rank in (0, 1):
+        assert np.array_equal(np.load(tmp_path / f"counters{rank}.npy"), one), rank
+    assert one[0] == 1400 and one[1] >= 1  # frame 1217 is the reference's first frame error at -4 dB (SURVEY §8c)
+
+
+def test_device_encoded_codewords_have_zero_syndrome(decg):
+    """What the reference's own unit test checks (tests/ldpctest.cpp: H * (u G) == 0), on the device encoder's
+    codewords — including the running accumulation over frames (channel.cpp:44-60) — and through the C-ABI
+    `syndrome` entry of the same library."""
+    code = orc.Code(orc.H_TXT, orc.G_TXT)
+    decg.stream_begin("BSC", 5, 0.05)
+    decg.stream_skip(3)
+    r = decg.stream_decode(40, want=("codeword", "iters"))
+    cw = r["codeword"]
+    assert cw.shape == (40, code.nc) and cw.any() and len({c.tobytes() for c in cw}) > 30
+    for c in cw:
+        assert not code.syndrome(c).any()

@@ -137,6 +137,11 @@ float ldpc_hip_last_ms(ldpc_hip_ctx *ctx, int which);
    generator (jump-ahead + parallel chunks); out is device or host memory */
 int ldpc_hip_mt64(ldpc_hip_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, uint64_t *out, void *hip_stream);
 
+/* self-test of the device arithmetic: n pseudo-random positive operand pairs (a, b) with a, b and a/b inside
+   2^-+1000 go through the division sequence the likelihood-ratio kernels use (detmath.h, dm_ratio_div) and through
+   the IEEE division; *mismatches receives the number of pairs whose quotients differ in any bit (expected: 0) */
+int ldpc_hip_selftest_division(ldpc_hip_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *mismatches);
+
 /* the simulation loop of ldpc_sim::start (ldpcsim.cpp:97-263) on one context; totals[4*i..] =
    {frames, fec, bec, iters} per channel point.  Returns the number of channel points, <0 on error. */
 int ldpc_hip_simulate(ldpc_hip_ctx *ctx, decoder_param dec, channel_param ch, simulation_param sim,

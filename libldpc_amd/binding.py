@@ -69,6 +69,8 @@ def load_library(path=LIB_PATH):
     L.ldpc_hip_stream_raw_draws.argtypes = [vp]
     L.ldpc_hip_synchronize.restype = i32
     L.ldpc_hip_synchronize.argtypes = [vp, vp]
+    L.ldpc_hip_selftest_division.restype = i32
+    L.ldpc_hip_selftest_division.argtypes = [vp, u64, u64, vp]
     L.ldpc_hip_mt64.restype = i32
     L.ldpc_hip_mt64.argtypes = [vp, u64, u64, u64, vp, vp]
     L.ldpc_hip_set_profiling.argtypes = [vp, i32]
@@ -181,6 +183,13 @@ class HipDecoder:
 
     def last_ms(self, which=0):
         return float(self.lib.ldpc_hip_last_ms(self.ctx, which))
+
+    def selftest_division(self, n, seed=1):
+        """Pairs (of n) on which the kernels' division sequence and the IEEE division disagree (expected 0)."""
+        bad = ct.c_uint64(0)
+        self._check(self.lib.ldpc_hip_selftest_division(self.ctx, int(n), int(seed), ct.byref(bad)),
+                    "ldpc_hip_selftest_division")
+        return bad.value
 
     def mt64(self, seed, first, n):
         out = np.zeros(int(n), np.uint64)

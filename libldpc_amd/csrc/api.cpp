@@ -310,6 +310,25 @@ int ldpc_hip_mt64(ldpc_hip_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, 
     });
 }
 
+int ldpc_hip_selftest_division(ldpc_hip_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *mismatches)
+{
+    return guarded([&] {
+        if (ldpc_hip_device_count() <= ctx->eng->device())
+            throw std::runtime_error("no usable HIP device (MI355X required)");
+        if (hipSetDevice(ctx->eng->device()) != hipSuccess)
+            throw std::runtime_error("hipSetDevice failed");
+        unsigned long long *d = nullptr, h = 0;
+        if (hipMalloc(&d, sizeof h) != hipSuccess || hipMemset(d, 0, sizeof h) != hipSuccess)
+            throw std::runtime_error("hipMalloc failed");
+        const int rc = ldpc_amd::launch_division_selftest(n, seed, d, nullptr);
+        const bool ok = rc == hipSuccess && hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(d);
+        if (!ok)
+            throw std::runtime_error("division self-test failed to run");
+        *mismatches = h;
+    });
+}
+
 int ldpc_hip_simulate(ldpc_hip_ctx *ctx, decoder_param dec, channel_param ch, simulation_param sim,
                       sim_results_t *results, uint64_t *totals, bool *stopFlag, int cli_output)
 {

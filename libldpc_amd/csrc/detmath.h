@@ -310,9 +310,34 @@ DM_FN double dm_e_to_llr(uint32_t sign_word, double e)
 #define DM_RATIO_LLR_LIMIT 166.0
 
 DM_FN int dm_ratio_out_of_range(double r) { return !(r <= DM_RATIO_HI && r >= DM_RATIO_LO); } /* NaN: out */
-DM_FN double dm_ratio_rho(double x, double y) { return DM_FMA(x, y, 1.0) / (x + y); }
-DM_FN double dm_ratio_lambda(double x, double y) { return (x + y) / DM_FMA(x, y, 1.0); }
+
+/*
+ * dm_ratio_div(a, b) = the correctly rounded quotient a / b for the operands this form produces: positive normal
+ * numbers with a, b and a/b all inside 2^-+1000 (guaranteed while the frame is inside the box; once a value has
+ * left it the frame's results are discarded, so what a division returns after that point does not matter, and the
+ * value that trips a range check is always a product, never a quotient).  On the host it is the IEEE division.
+ * On the device it is the hardware's own division sequence (reciprocal estimate, two Newton steps, quotient,
+ * one correction: what the compiler emits for `/`) without the operand pre-scaling and special-case fix-up, which
+ * are the identity for such operands: 8 instructions instead of 11, same bits.
+ */
+DM_FN double dm_ratio_div(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(b);
+    double e = DM_FMA(-b, r, 1.0);
+    r = DM_FMA(r, e, r);
+    e = DM_FMA(-b, r, 1.0);
+    r = DM_FMA(r, e, r);
+    double q = a * r;
+    double t = DM_FMA(-b, q, a);
+    return DM_FMA(t, r, q);
+#else
+    return a / b;
+#endif
+}
+DM_FN double dm_ratio_rho(double x, double y) { return dm_ratio_div(DM_FMA(x, y, 1.0), x + y); }
+DM_FN double dm_ratio_lambda(double x, double y) { return dm_ratio_div(x + y, DM_FMA(x, y, 1.0)); }
 /* the same two with one operand given as a fraction n/d (a partial result not yet divided) */
-DM_FN double dm_ratio_lambda_frac(double n, double d, double y) { return DM_FMA(d, y, n) / DM_FMA(n, y, d); }
+DM_FN double dm_ratio_lambda_frac(double n, double d, double y) { return dm_ratio_div(DM_FMA(d, y, n), DM_FMA(n, y, d)); }
 
 #endif /* LDPC_AMD_DETMATH_H */

@@ -80,7 +80,7 @@ __device__ __forceinline__ void cn_ratio(double (&v)[D])
 {
     if constexpr (D == 2)
     {
-        const double a = 1.0 / v[1], b = 1.0 / v[0];
+        const double a = dm_ratio_div(1.0, v[1]), b = dm_ratio_div(1.0, v[0]);
         v[0] = a, v[1] = b;
     }
     else if constexpr (D == 3)

@@ -18,6 +18,7 @@
 //   bit-error count        src/sim/ldpcsim.cpp:184-188
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "device_channel.hpp"
@@ -242,7 +243,7 @@ __device__ __forceinline__ double vn_update_ratio(double *msg, const uint32_t *i
             escaped |= dm_ratio_out_of_range(prod);
     }
     const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u; // total LLR <= 0: hard decision 1
-    const double tot = 1.0 / prod;                        // rho(total)
+    const double tot = dm_ratio_div(1.0, prod);                        // rho(total)
 #pragma unroll
     for (int p = 0; p < DV; ++p)
     {
@@ -270,7 +271,7 @@ __device__ __forceinline__ double vn_small_ratio(double *msg, uint32_t packed, d
     for (int p = 0; p < DV; ++p)
         prod *= c[p];
     const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u;
-    const double tot = 1.0 / prod;
+    const double tot = dm_ratio_div(1.0, prod);
 #pragma unroll
     for (int p = 0; p < DV; ++p)
     {
@@ -296,7 +297,7 @@ __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, 
     for (int p = 0; p < DV; ++p)
         pa *= ca[p], pb *= cb[p];
     const uint32_t sga = pa >= 1.0 ? 0x80000000u : 0u, sgb = pb >= 1.0 ? 0x80000000u : 0u;
-    const double ta = 1.0 / pa, tb = 1.0 / pb;
+    const double ta = dm_ratio_div(1.0, pa), tb = dm_ratio_div(1.0, pb);
 #pragma unroll
     for (int p = 0; p < DV; ++p)
     {
@@ -326,7 +327,7 @@ __device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32
             escaped |= dm_ratio_out_of_range(prod);
     }
     const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u;
-    const double tot = 1.0 / prod;
+    const double tot = dm_ratio_div(1.0, prod);
 #pragma unroll
     for (int p = 0; p < DV; ++p)
     {
@@ -421,7 +422,7 @@ __device__ __forceinline__ double vn_block_ratio(double *msg, const uint32_t *id
     default: break;
     }
     const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u;
-    const double tot = 1.0 / prod;
+    const double tot = dm_ratio_div(1.0, prod);
     for (p0 = 0; p0 + 8 <= degree; p0 += 8)
         vn_ratio_pass2<8>(msg, idx, count, p0, tot, sign, escaped);
     switch (degree - p0)
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
     // ---- v2c initialisation: decoder.cpp:16-19 ----
     for_my_vn_blocks([&](const VnBlock &b, double L) {
         const uint32_t *idx = P.vn_slot + b.idx_off + lane;
-        const double v0 = RATIO ? 1.0 / L : L; // RATIO: L is lambda(L_ch), the first v2c is rho(L_ch)
+        const double v0 = RATIO ? dm_ratio_div(1.0, L) : L; // RATIO: L is lambda(L_ch), the first v2c is rho(L_ch)
         for (int p = 0; p < b.degree; ++p)
             msg[idx[p * b.count]] = v0;
     });
@@ -1202,6 +1203,29 @@ __global__ __launch_bounds__(256) void encode_cw_kernel(const EncodeArgs a, uint
     }
 }
 
+// operands a = 2^ea * ma, b = 2^eb * mb with ea, eb in [-500, 500] and random mantissas: a, b, a/b inside 2^-+1001
+__global__ __launch_bounds__(256) void division_selftest_kernel(uint64_t n, uint64_t seed, unsigned long long *mismatches)
+{
+    unsigned long long bad = 0;
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull)
+    {
+        uint64_t x = (i + 1) * 0x9E3779B97F4A7C15ull ^ seed;
+        auto next = [&] {
+            x ^= x >> 12, x ^= x << 25, x ^= x >> 27;
+            return x * 0x2545F4914F6CDD1Dull;
+        };
+        auto operand = [&] {
+            const uint64_t m = next() >> 12, e = 1023 - 500 + (next() >> 33) % 1001;
+            return dm_from_bits((e << 52) | m);
+        };
+        const double a = operand(), b = operand();
+        volatile double bv = b; // keep the compiler from folding the two forms together
+        bad += dm_bits(dm_ratio_div(a, b)) != dm_bits(a / bv);
+    }
+    if (bad)
+        atomicAdd(mismatches, bad);
+}
+
 template <bool LDS_RESIDENT, int MAXD, int LLR_MODE>
 int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *stream)
 {
@@ -1271,6 +1295,16 @@ int launch_decode_mem(const DecodeArgs &a, bool min_sum, int max_cn_degree, uint
     if (max_cn_degree <= 16)
         return launch_decode<false, 16, kLlrMem>(a, min_sum, occupancy_lds, stream);
     return hipErrorInvalidValue;
+}
+
+int launch_division_selftest(uint64_t n, uint64_t seed, unsigned long long *mismatches, void *stream)
+{
+    if (n == 0)
+        return hipSuccess;
+    const unsigned blocks = static_cast<unsigned>(std::min<uint64_t>((n + 255) / 256, 8192));
+    hipLaunchKernelGGL(division_selftest_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), n, seed,
+                       mismatches);
+    return hipGetLastError();
 }
 
 int launch_bec(const BecArgs &a, void *stream)

@@ -167,4 +167,7 @@ struct EncodeArgs
 };
 int launch_encode(const EncodeArgs &a, void *stream);
 
+// dm_ratio_div vs the IEEE division on n pseudo-random operand pairs; *mismatches (device, zeroed by the caller)
+int launch_division_selftest(uint64_t n, uint64_t seed, unsigned long long *mismatches, void *stream);
+
 } // namespace ldpc_amd

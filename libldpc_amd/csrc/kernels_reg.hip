@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
             if (lane < vb.count)
             {
                 const double L = llr[vb.first + lane];
-                const double v0 = RATIO ? 1.0 / L : L; // RATIO: L is lambda(L_ch), the first v2c is rho(L_ch)
+                const double v0 = RATIO ? dm_ratio_div(1.0, L) : L; // RATIO: L is lambda(L_ch), the first v2c is rho(L_ch)
                 for (int p = 0; p < vb.degree; ++p)
                     mb[vb.mb_off + p * vb.count + lane] = v0;
             }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
                                         escaped |= dm_ratio_out_of_range(prod);
                                 }
                             const uint8_t bit = prod >= 1.0; // total LLR <= 0
-                            const double tot = 1.0 / prod;   // rho(total)
+                            const double tot = dm_ratio_div(1.0, prod);   // rho(total)
                             for (int p = 0; p < vb.degree; ++p)
                             {
                                 const double o = tot * col[p * vb.count]; // rho(total - c2v_p)

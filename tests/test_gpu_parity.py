@@ -190,3 +190,11 @@ def test_batch_split_is_invisible(dec):
     parts = [dec.stream_decode(n, decoding="BP_MS") for n in (1, 7, 92, 200)]
     assert np.array_equal(a["iters"], np.concatenate([p["iters"] for p in parts]))
     assert np.array_equal(a["bit_errors"], np.concatenate([p["bit_errors"] for p in parts]))
+
+
+def test_division_sequence_is_the_ieee_division(dec):
+    """The likelihood-ratio kernels divide with the hardware's division sequence minus operand scaling and
+    special-case fix-up (detmath.h, dm_ratio_div): identical to the correctly rounded quotient on every one of
+    2^27 operand pairs spread over the whole exponent range the form can produce."""
+    assert dec.selftest_division(1 << 27, seed=7) == 0
+    assert dec.selftest_division(1 << 20, seed=12345) == 0

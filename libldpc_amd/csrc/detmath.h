@@ -236,6 +236,8 @@ DM_FN double dm_boxplus_log(double q)
     return w + l;
 }
 
+DM_FN double dm_ratio_div(double a, double b); /* below: the IEEE quotient for positive in-range operands */
+
 DM_FN double dm_boxplus(double x, double y)
 {
     double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
@@ -244,7 +246,7 @@ DM_FN double dm_boxplus(double x, double y)
     double m = dm_from_bits(dm_bits(mn) | sgn); /* sign(x) sign(y) min: -0.0 when the signs differ and min is 0 */
     double num = 1.0 + dm_boxplus_exp(__builtin_fabs(x + y));
     double den = 1.0 + dm_boxplus_exp(__builtin_fabs(x - y));
-    return m + dm_boxplus_log(num / den);
+    return m + dm_boxplus_log(dm_ratio_div(num, den)); /* both in [1, 2] */
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -273,7 +275,7 @@ DM_FN double dm_boxplus(double x, double y)
  * ------------------------------------------------------------------------------------------------ */
 #define DM_SHARED_LIMIT 600.0
 
-DM_FN double dm_e_combine(double ex, double ey) { return (ex + ey) / DM_FMA(ex, ey, 1.0); }
+DM_FN double dm_e_combine(double ex, double ey) { return dm_ratio_div(ex + ey, DM_FMA(ex, ey, 1.0)); } /* E >= e^-600 */
 
 /* LLR of a partial result carried as (sign bit, E): s * (-log E); an exact zero comes out as +0.0, as in
    the reference where log(1) = +0.0 is added to a signed zero */

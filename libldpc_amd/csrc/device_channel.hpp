@@ -42,15 +42,14 @@ __device__ __forceinline__ void channel_init(const DecodeArgs &a, uint64_t frame
         if (a.mode == kModeAwgn)
         {
             // normal g of the stream is element (g & 1) of accepted polar pair g >> 1:
-            // element 0 = y*mult, element 1 = x*mult (libstdc++ returns y first and saves x)
+            // element 0 = y*mult, element 1 = x*mult (libstdc++ returns y first and saves x; channel.cpp:62-68)
             const uint64_t g0 = a.normal_base + frame * static_cast<uint64_t>(nct);
             const uint64_t q_lo = g0 >> 1, q_hi = (g0 + nct - 1) >> 1;
             for (uint64_t q = q_lo + tid; q <= q_hi; q += kThreads)
             {
-                const uint64_t *pp = a.pairs + 2 * (q - a.pair_base);
-                PolarTrial t = polar_trial(pp[0], pp[1]);
-                double mult = __builtin_sqrt(-2 * dm_log(t.r2) / t.r2);
-                double nrm[2] = {t.y * mult, t.x * mult};
+                // the noise-stream kernels (polar_compact_kernel) already turned the accepted trial into its normals
+                const ulonglong2 pp = *reinterpret_cast<const ulonglong2 *>(a.pairs + 2 * (q - a.pair_base));
+                const double nrm[2] = {dm_from_bits(pp.x), dm_from_bits(pp.y)};
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
                 {

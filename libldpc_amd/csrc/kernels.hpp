@@ -45,7 +45,7 @@ struct DecodeArgs
     uint64_t n_frames;
     // kModeLlr
     const double *llr_in; // [n_frames][nc], column order
-    // kModeAwgn: accepted polar pairs (raw 64-bit draws u1,u2) of the normal stream; pair q of the
+    // kModeAwgn: the two normals (bit patterns of y*mult, x*mult) of every accepted polar pair of the stream; pair q of the
     // stream sits at pairs[2*(q - pair_base)], normal g = frame*nct + i comes from pair g>>1.
     const uint64_t *pairs;
     uint64_t pair_base;

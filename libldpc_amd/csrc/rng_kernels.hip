@@ -288,8 +288,15 @@ __global__ __launch_bounds__(kScanThreads) void polar_compact_kernel(const uint6
                     uint64_t t = base + it * kScanThreads + tid;
                     if (pairs_out)
                     {
+                        // the accepted trial leaves here as its two normals (libstdc++ normal_distribution, polar
+                        // method: y*mult is returned first, x*mult saved for the next call), so the decode launch
+                        // finds finished variates instead of a log/divide/sqrt chain at the head of every frame
                         const ulonglong2 u = *reinterpret_cast<const ulonglong2 *>(raw + 2 * t);
-                        *reinterpret_cast<ulonglong2 *>(pairs_out + 2 * rank) = u;
+                        const PolarTrial tr = polar_trial(u.x, u.y);
+                        const double mult = __builtin_sqrt(-2 * dm_log(tr.r2) / tr.r2);
+                        ulonglong2 o;
+                        o.x = dm_bits(tr.y * mult), o.y = dm_bits(tr.x * mult);
+                        *reinterpret_cast<ulonglong2 *>(pairs_out + 2 * rank) = o;
                     }
                     if (rank == want - 1)
                         result->trials_used = t + 1;

@@ -302,7 +302,7 @@ DM_FN double dm_e_to_llr(uint32_t sign_word, double e)
  * of a ratio (= the absolute error of its LLR) stays at a few 1e-16 per operation.
  *
  * binary64 holds e^L only for |L| < 709, so this form is valid while every message stays inside
- * [DM_RATIO_LO, DM_RATIO_HI] = 2^-+240 (|L| <= 166.3) and every channel LLR within DM_RATIO_LLR_LIMIT; a
+ * [DM_RATIO_LO, DM_RATIO_HI) = 2^-+240 (|L| < 166.4) and every channel LLR within DM_RATIO_LLR_LIMIT; a
  * frame that leaves that box at any point is decoded from scratch with the LLR-domain form above (dm_boxplus /
  * dm_e_combine).  The rule is per frame and depends on nothing but the frame's own data.  Products of up to
  * four in-range factors stay normal numbers (2^-+960); longer products are range-checked every third factor.
@@ -311,7 +311,18 @@ DM_FN double dm_e_to_llr(uint32_t sign_word, double e)
 #define DM_RATIO_LO 0x1p-240
 #define DM_RATIO_LLR_LIMIT 166.0
 
-DM_FN int dm_ratio_out_of_range(double r) { return !(r <= DM_RATIO_HI && r >= DM_RATIO_LO); } /* NaN: out */
+DM_FN int dm_ratio_out_of_range(double r) { return !(r >= DM_RATIO_LO && r < DM_RATIO_HI); } /* NaN: out */
+/*
+ * The same predicate on the upper word of the bit pattern (positive doubles order like their bit patterns, and both
+ * bounds are powers of two, so the lower word never matters): r is outside [2^-240, 2^240) exactly when
+ * dm_ratio_key(r) >= DM_RATIO_KEY_SPAN in unsigned arithmetic — zero, denormals, negative numbers, infinities
+ * and NaNs included.  The kernels keep the running maximum of the keys (DM_RATIO_TRACK) and compare once per pass.
+ */
+#define DM_RATIO_KEY_LO ((1023u - 240u) << 20)
+#define DM_RATIO_KEY_SPAN (480u << 20)
+DM_FN uint32_t dm_ratio_key(double r) { return (uint32_t)(dm_bits(r) >> 32) - DM_RATIO_KEY_LO; }
+#define DM_RATIO_TRACK(acc, r) ((acc) = (acc) > dm_ratio_key(r) ? (acc) : dm_ratio_key(r))
+#define DM_RATIO_ESCAPED(acc) ((acc) >= DM_RATIO_KEY_SPAN)
 
 /*
  * dm_ratio_div(a, b) = the correctly rounded quotient a / b for the operands this form produces: positive normal

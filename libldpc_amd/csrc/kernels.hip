@@ -225,7 +225,7 @@ __device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b,
 // lambda(total) = lam * prod_p lambda(c2v_p) in column file order; v2c_p = lambda(c2v_p) / lambda(total).
 // Returns lambda(total); the hard decision (total LLR <= 0) goes into the sign bit of every v2c written.
 template <int DV>
-__device__ __forceinline__ double vn_update_ratio(double *msg, const uint32_t *idx, int count, double lam, int &escaped)
+__device__ __forceinline__ double vn_update_ratio(double *msg, const uint32_t *idx, int count, double lam, uint32_t &escaped)
 {
     uint32_t s[DV];
     double c[DV];
@@ -241,7 +241,7 @@ __device__ __forceinline__ double vn_update_ratio(double *msg, const uint32_t *i
     {
         prod *= c[p];
         if (DV > 3 && p % 3 == 2)
-            escaped |= dm_ratio_out_of_range(prod);
+            DM_RATIO_TRACK(escaped, prod);
     }
     const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u; // total LLR <= 0: hard decision 1
     const double tot = dm_ratio_div(1.0, prod);                        // rho(total)
@@ -249,7 +249,7 @@ __device__ __forceinline__ double vn_update_ratio(double *msg, const uint32_t *i
     for (int p = 0; p < DV; ++p)
     {
         const double o = tot * c[p]; // rho(total - c2v_p)
-        escaped |= dm_ratio_out_of_range(o);
+        DM_RATIO_TRACK(escaped, o);
         msg[s[p]] = with_sign(o, sign);
     }
     return prod;
@@ -259,7 +259,7 @@ __device__ __forceinline__ double vn_update_ratio(double *msg, const uint32_t *i
 // one node or two independent nodes (of two blocks) in lock step: no table load in front of the LDS round trip,
 // two chains in flight
 template <int DV>
-__device__ __forceinline__ double vn_small_ratio(double *msg, uint32_t packed, double lam, int &escaped)
+__device__ __forceinline__ double vn_small_ratio(double *msg, uint32_t packed, double lam, uint32_t &escaped)
 {
     static_assert(DV >= 1 && DV <= 2, "register-held slot indices");
     const uint32_t sl[2] = {packed & 0xFFFFu, packed >> 16};
@@ -277,7 +277,7 @@ __device__ __forceinline__ double vn_small_ratio(double *msg, uint32_t packed, d
     for (int p = 0; p < DV; ++p)
     {
         const double o = tot * c[p];
-        escaped |= dm_ratio_out_of_range(o);
+        DM_RATIO_TRACK(escaped, o);
         msg[sl[p]] = with_sign(o, sign);
     }
     return prod;
@@ -285,7 +285,7 @@ __device__ __forceinline__ double vn_small_ratio(double *msg, uint32_t packed, d
 
 template <int DV>
 __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, uint32_t packed_b, double la, double lb,
-                                                int &escaped, double &pa, double &pb)
+                                                uint32_t &escaped, double &pa, double &pb)
 {
     static_assert(DV >= 1 && DV <= 2, "register-held slot indices");
     const uint32_t sa[2] = {packed_a & 0xFFFFu, packed_a >> 16}, sb[2] = {packed_b & 0xFFFFu, packed_b >> 16};
@@ -303,7 +303,7 @@ __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, 
     for (int p = 0; p < DV; ++p)
     {
         const double oa = ta * ca[p], ob = tb * cb[p];
-        escaped |= dm_ratio_out_of_range(oa) | dm_ratio_out_of_range(ob);
+        DM_RATIO_TRACK(escaped, oa), DM_RATIO_TRACK(escaped, ob);
         msg[sa[p]] = with_sign(oa, sga);
         msg[sb[p]] = with_sign(ob, sgb);
     }
@@ -312,7 +312,7 @@ __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, 
 // A node of up to 16 edges whose slot indices the lane keeps in registers (16 x u16 in eight words, kLlrRegs: the
 // first — widest — VN block of every wave): no table load at all, every message read once.
 template <int DV>
-__device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32_t (&packed)[8], double lam, int &escaped)
+__device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32_t (&packed)[8], double lam, uint32_t &escaped)
 {
     auto slot = [&](int p) { return (p & 1) ? packed[p >> 1] >> 16 : packed[p >> 1] & 0xFFFFu; };
     double c[DV];
@@ -325,7 +325,7 @@ __device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32
     {
         prod *= c[p];
         if (DV > 3 && p % 3 == 2)
-            escaped |= dm_ratio_out_of_range(prod);
+            DM_RATIO_TRACK(escaped, prod);
     }
     const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u;
     const double tot = dm_ratio_div(1.0, prod);
@@ -333,14 +333,14 @@ __device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32
     for (int p = 0; p < DV; ++p)
     {
         const double o = tot * c[p];
-        escaped |= dm_ratio_out_of_range(o);
+        DM_RATIO_TRACK(escaped, o);
         msg[slot(p)] = with_sign(o, sign);
     }
     return prod;
 }
 
 __device__ __forceinline__ double vn_block_ratio_regs(double *msg, const uint32_t (&packed)[8], int degree, double lam,
-                                                      int &escaped)
+                                                      uint32_t &escaped)
 {
     switch (degree) // wave-uniform, 1..16
     {
@@ -357,7 +357,7 @@ __device__ __forceinline__ double vn_block_ratio_regs(double *msg, const uint32_
 // running product (range check at every third position of the node, as everywhere), pass 2 writes N messages
 template <int N>
 __device__ __forceinline__ void vn_ratio_pass1(const double *msg, const uint32_t *idx, int count, int p0, double &prod,
-                                               int &escaped)
+                                               uint32_t &escaped)
 {
     uint32_t s[N];
     double c[N];
@@ -373,13 +373,13 @@ __device__ __forceinline__ void vn_ratio_pass1(const double *msg, const uint32_t
     {
         prod *= c[p];
         if ((ph + p) % 3 == 2)
-            escaped |= dm_ratio_out_of_range(prod);
+            DM_RATIO_TRACK(escaped, prod);
     }
 }
 
 template <int N>
 __device__ __forceinline__ void vn_ratio_pass2(double *msg, const uint32_t *idx, int count, int p0, double tot,
-                                               uint32_t sign, int &escaped)
+                                               uint32_t sign, uint32_t &escaped)
 {
     uint32_t s[N];
     double c[N];
@@ -393,13 +393,13 @@ __device__ __forceinline__ void vn_ratio_pass2(double *msg, const uint32_t *idx,
     for (int p = 0; p < N; ++p)
     {
         const double o = tot * c[p];
-        escaped |= dm_ratio_out_of_range(o);
+        DM_RATIO_TRACK(escaped, o);
         msg[s[p]] = with_sign(o, sign);
     }
 }
 
 __device__ __forceinline__ double vn_block_ratio(double *msg, const uint32_t *idx, int count, int degree, double lam,
-                                                 int &escaped)
+                                                 uint32_t &escaped)
 {
     switch (degree) // wave-uniform
     {
@@ -577,7 +577,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 
     const auto my_vn = uniform_table(P.vn_work + wave * P.vn_work_stride);
     const auto my_cn = uniform_table(P.cn_work + wave * P.cn_work_stride);
-    int escaped = 0; // RATIO: some value of this frame left the representable box
+    uint32_t escaped = 0; // RATIO: running maximum of dm_ratio_key over the frame's checked values (detmath.h)
     if constexpr (RATIO && LLR_MODE != kLlrRegs)
     {
         // input LLRs become lambda = e^-L in place (isolated variable nodes keep their LLR: nothing multiplies it)
@@ -585,7 +585,8 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             if (P.rank_slot0[r] != kNoSlot)
             {
                 const double L = llr[r];
-                escaped |= !(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT);
+                if (!(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT))
+                    escaped = ~0u;
                 llr[r] = dm_exp(0.0 - L);
             }
         __syncthreads();
@@ -614,7 +615,8 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                         my_llr[w] = llr[b.first + lane];
                         if constexpr (RATIO)
                         {
-                            escaped |= !(__builtin_fabs(my_llr[w]) <= DM_RATIO_LLR_LIMIT);
+                            if (!(__builtin_fabs(my_llr[w]) <= DM_RATIO_LLR_LIMIT))
+                                escaped = ~0u;
                             my_llr[w] = dm_exp(0.0 - my_llr[w]);
                             const uint32_t *idx = P.vn_slot + b.idx_off + lane; // LDS-resident: every slot < 2^16
                             if (b.degree >= 1 && b.degree <= 2)
@@ -703,7 +705,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     bad |= cn_block_ratio<MAXD>(msg, b0, lane) | cn_block_ratio<MAXD>(msg, b1, lane);
             }
             const int ph = I & 1;
-            const int wave_vote = (__ballot(bad != 0) != 0) | ((__ballot(escaped != 0) != 0) << 1);
+            const int wave_vote = (__ballot(bad != 0) != 0) | ((__ballot(DM_RATIO_ESCAPED(escaped)) != 0) << 1);
             if (lane == 0)
                 votes[ph][wave] = wave_vote;
             __syncthreads();

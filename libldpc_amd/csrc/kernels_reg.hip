@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
         for (int r = tid; r < nc; r += NT)
             o[P.rank_col[r]] = llr[r];
     }
-    int escaped = 0; // RATIO: some value of this frame left the representable box
+    uint32_t escaped = 0; // RATIO: running maximum of dm_ratio_key over the frame's checked values (detmath.h)
     if constexpr (RATIO)
     {
         // input LLRs become lambda = e^-L in place (isolated variable nodes keep their LLR)
@@ -127,7 +127,8 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
             if (P.rank_slot0[r] != kNoSlot)
             {
                 const double L = llr[r];
-                escaped |= !(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT);
+                if (!(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT))
+                    escaped = ~0u;
                 llr[r] = dm_exp(0.0 - L);
             }
         __syncthreads();
@@ -223,14 +224,14 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
                                 {
                                     prod *= col[p * vb.count];
                                     if (p % 3 == 2)
-                                        escaped |= dm_ratio_out_of_range(prod);
+                                        DM_RATIO_TRACK(escaped, prod);
                                 }
                             const uint8_t bit = prod >= 1.0; // total LLR <= 0
                             const double tot = dm_ratio_div(1.0, prod);   // rho(total)
                             for (int p = 0; p < vb.degree; ++p)
                             {
                                 const double o = tot * col[p * vb.count]; // rho(total - c2v_p)
-                                escaped |= dm_ratio_out_of_range(o);
+                                DM_RATIO_TRACK(escaped, o);
                                 col[p * vb.count] = o;
                                 hcol[p * vb.count] = bit;
                             }
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
         }
         // ---- syndrome early termination (decoder.cpp:66-72, decoder.h:47-64) ----
         if constexpr (RATIO)
-            if (__syncthreads_or(escaped)) // checked before the syndrome: an escaped frame's hard decisions mean nothing
+            if (__syncthreads_or(DM_RATIO_ESCAPED(escaped))) // checked before the syndrome: an escaped frame's hard decisions mean nothing
             {
                 if (tid == 0)
                     a.redo_list[atomicAdd(a.redo_count, 1u)] = static_cast<uint32_t>(frame);

@@ -262,6 +262,7 @@ template <int DV>
 __device__ __forceinline__ double vn_small_ratio(double *msg, uint32_t packed, double lam, uint32_t &escaped)
 {
     static_assert(DV >= 1 && DV <= 2, "register-held slot indices");
+    asm volatile("" : "+v"(packed)); // unpack here, every iteration: the packed word is what stays live
     const uint32_t sl[2] = {packed & 0xFFFFu, packed >> 16};
     double c[DV];
 #pragma unroll
@@ -288,6 +289,7 @@ __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, 
                                                 uint32_t &escaped, double &pa, double &pb)
 {
     static_assert(DV >= 1 && DV <= 2, "register-held slot indices");
+    asm volatile("" : "+v"(packed_a), "+v"(packed_b)); // unpack here, every iteration
     const uint32_t sa[2] = {packed_a & 0xFFFFu, packed_a >> 16}, sb[2] = {packed_b & 0xFFFFu, packed_b >> 16};
     double ca[DV], cb[DV];
 #pragma unroll
@@ -314,7 +316,16 @@ __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, 
 template <int DV>
 __device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32_t (&packed)[8], double lam, uint32_t &escaped)
 {
-    auto slot = [&](int p) { return (p & 1) ? packed[p >> 1] >> 16 : packed[p >> 1] & 0xFFFFu; };
+    // the words stay packed across iterations: without the barrier the compiler hoists all 16 unpacked indices out
+    // of the decode loop and keeps them live for the whole kernel
+    uint32_t pk[(DV + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (DV + 1) / 2; ++i)
+    {
+        pk[i] = packed[i];
+        asm volatile("" : "+v"(pk[i]));
+    }
+    auto slot = [&](int p) { return (p & 1) ? pk[p >> 1] >> 16 : pk[p >> 1] & 0xFFFFu; };
     double c[DV];
 #pragma unroll
     for (int p = 0; p < DV; ++p)
@@ -912,13 +923,6 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
     decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO>(a);
 }
 
-// the same body compiled for five waves per SIMD (<= 96 VGPRs): five LDS-resident frames per CU
-template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void decode_kernel_occ5(const DecodeArgs a)
-{
-    decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO>(a);
-}
-
 // ---------------------------------------------------------------------------------------------
 // BEC: erasure decoder over the alphabet {0, 1, 'E'} (decoder.cpp:91-192), channel fused
 // (channel.cpp:199-229).  All state is bytes in LDS: msg[nnz], sym[nc] (decoder input), lout[nc].
@@ -1257,13 +1261,6 @@ int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *s
     {
         k = want_llr ? decode_kernel<false, true, LDS_RESIDENT, MAXD, LLR_MODE, true>
                      : decode_kernel<false, false, LDS_RESIDENT, MAXD, LLR_MODE, true>;
-        // Narrow codes whose frames fit LDS five at a time: the build capped at 96 VGPRs (it spills ~17 dwords of
-        // the register-held indices) runs five frames per CU and measures ~4 % faster than four frames at 121 VGPRs.
-        if constexpr (LDS_RESIDENT && MAXD == 4 && LLR_MODE == kLlrRegs)
-        {
-            if (!want_llr && 5u * (lds_bytes + 64u) <= 160u * 1024u && !std::getenv("LDPC_AMD_NO_OCC5"))
-                k = decode_kernel_occ5<false, false, LDS_RESIDENT, MAXD, LLR_MODE, true>;
-        }
     }
     else
     {

@@ -87,8 +87,8 @@ def cpu_baseline(seconds_budget=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--decoding", default="BP")
     ap.add_argument("--no-early-term", action="store_true")

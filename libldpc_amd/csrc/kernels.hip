@@ -1,11 +1,16 @@
 // kernels.hip — hand-written HIP kernels for gfx950 (MI355X, wave64).
 //
 // Hot path of heat1q/libldpc rebuilt for CDNA4: flooding BP (sum-product / min-sum) with the
-// channel + LLR initialisation fused into the same launch.  One workgroup decodes one frame;
-// thousands of frames per launch.  Two residencies of the per-frame state share one kernel body:
-//   LDS-resident     (n=1024 test code: 40 KB per frame, 4 frames per CU)
-//   memory-resident  (codes that do not fit LDS, e.g. n=8192: the frames in flight are sized to stay
-//                     inside the 256 MiB Infinity Cache)
+// channel + LLR initialisation fused into the same launch.  One workgroup (4 waves) decodes one frame;
+// tens of thousands of frames per launch.  Two residencies of the per-frame state share one kernel body
+// (a third, register-resident, lives in kernels_reg.hip):
+//   LDS-resident     (n=1024 test code: 27 KB of messages per frame, input LLRs in registers, five frames per CU)
+//   memory-resident  (codes that fit neither LDS nor the register-resident kernel: the frames in flight are
+//                     sized to stay inside the 256 MiB Infinity Cache)
+// and two algebraically equal forms of the sum-product iteration (detmath.h):
+//   likelihood-ratio form (RATIO)  BP with early termination: messages e^L / e^-L, no exp/log in the loop, hard
+//                                  decisions in the sign bits of the messages, syndrome fused into the CN pass
+//   LLR-domain form                BP without early termination, frames the ratio form hands back, min-sum
 //
 // Reference semantics restated here (file:line in heat1q/libldpc):
 //   decode loop            src/decoding/decoder.cpp:11-78

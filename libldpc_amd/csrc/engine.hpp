@@ -64,7 +64,7 @@ class DeviceBuffer
 class MtStream
 {
   public:
-    static constexpr uint64_t kChunkWords = 840 * kMtWords; // 262080
+    static constexpr uint64_t kChunkWords = 3360 * kMtWords; // 1048320 words = 8 MB per chunk
     static constexpr uint32_t kStateCap = 8192;
     void reset(uint64_t seed);
     uint64_t seed() const { return seed_; }

@@ -198,3 +198,45 @@ def test_division_sequence_is_the_ieee_division(dec):
     2^27 operand pairs spread over the whole exponent range the form can produce."""
     assert dec.selftest_division(1 << 27, seed=7) == 0
     assert dec.selftest_division(1 << 20, seed=12345) == 0
+
+
+def _oracle_chunk(args):
+    """Worker (CPU only): frames [skip, skip+count) of the stream through the det-mode oracle."""
+    x, seed, skip, count = args
+    o = orc.Code(orc.H_TXT).run_frames("AWGN", x, seed=seed, skip=skip, count=count, math=orc.MATH_DET,
+                                       want_vectors=False)
+    return o["iters"], o["bit_errors"]
+
+
+def test_bulk_131072_frames_bit_exact_vs_det_oracle(dec):
+    """Two full batches of the headline workload (131 072 consecutive frames at -4 dB: ≈180 of them fail, ≈100 run
+    all 50 iterations): iteration count and bit-error count of every frame equal the oracle's.  The oracle side
+    runs in 16 CPU processes over disjoint frame ranges (its RNG-only skip makes that cheap)."""
+    import multiprocessing as mp
+    n, parts = 131072, 16
+    per = n // parts
+    with mp.get_context("fork").Pool(parts) as pool:
+        res = pool.map(_oracle_chunk, [(-4.0, 0, k * per, per) for k in range(parts)])
+    it = np.concatenate([r[0] for r in res])
+    be = np.concatenate([r[1] for r in res])
+    dec.stream_begin("AWGN", 0, -4.0)
+    r = dec.stream_decode(n, want=("iters", "bit_errors"))
+    assert np.array_equal(r["iters"], it)
+    assert np.array_equal(r["bit_errors"], be)
+    assert 100 <= int((be > 0).sum()) <= 300 and int((it >= 50).sum()) >= 30
+
+
+def test_bulk_100000_frames_vs_reference(dec, golden_bulk):
+    """100 000 consecutive frames against the reference's own per-frame counters (tests/golden/ref_bulk.npz, 132
+    frame errors, 7 of them undetected): on every frame the reference converged on — right or wrong codeword — the
+    iteration count and the bit-error count are identical, and exactly the same frames are in error."""
+    ref_it, ref_be = golden_bulk["iters"], golden_bulk["bit_errors"]
+    n = len(ref_it)
+    dec.stream_begin("AWGN", 0, -4.0)
+    r = dec.stream_decode(n, want=("iters", "bit_errors"))
+    conv = ref_it < 50
+    assert int(conv.sum()) == n - 125
+    assert np.array_equal(r["iters"][conv], ref_it[conv])
+    assert np.array_equal(r["bit_errors"][conv], ref_be[conv])
+    assert np.array_equal(r["bit_errors"] > 0, ref_be > 0)
+    assert np.array_equal(r["iters"] >= 50, ~conv)

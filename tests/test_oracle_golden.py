@@ -145,3 +145,31 @@ def test_shortened_code_frames_bit_exact(hshort_file, golden_frames, golden_sim)
         for k in ("iters", "bit_errors", "hard", "llr_in", "llr_out", "codeword"):
             ref = golden_frames[f"short/{name}/{k}"]
             assert np.array_equal(ref, r[k].astype(ref.dtype)), f"{name}/{k}"
+
+
+def _bulk_chunk(args):
+    math, skip, count = args
+    o = orc.Code(orc.H_TXT).run_frames("AWGN", -4.0, seed=0, skip=skip, count=count, math=math, want_vectors=False)
+    return o["iters"], o["bit_errors"]
+
+
+def test_bulk_reference_counters(golden_bulk):
+    """First 40 000 frames of the headline workload against the reference's own per-frame counters
+    (tests/golden/ref_bulk.npz): the libm-mode oracle equals them on every frame, failing ones included; the
+    det-mode oracle (the arithmetic of the HIP kernels: likelihood-ratio form, deterministic exp/log) equals them on
+    every frame the reference converged on and fails exactly the same frames."""
+    import multiprocessing as mp
+    n, parts = 40000, 8
+    per = n // parts
+    ref_it, ref_be = golden_bulk["iters"][:n], golden_bulk["bit_errors"][:n]
+    with mp.get_context("fork").Pool(parts) as pool:
+        libm = pool.map(_bulk_chunk, [(orc.MATH_LIBM, k * per, per) for k in range(parts)])
+        det = pool.map(_bulk_chunk, [(orc.MATH_DET, k * per, per) for k in range(parts)])
+    it = np.concatenate([r[0] for r in libm])
+    be = np.concatenate([r[1] for r in libm])
+    assert np.array_equal(it, ref_it) and np.array_equal(be, ref_be)
+    it = np.concatenate([r[0] for r in det])
+    be = np.concatenate([r[1] for r in det])
+    conv = ref_it < 50
+    assert np.array_equal(it[conv], ref_it[conv]) and np.array_equal(be[conv], ref_be[conv])
+    assert np.array_equal(be > 0, ref_be > 0)

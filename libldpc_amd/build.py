@@ -24,6 +24,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # depend on the compiler's contraction choices.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+if os.environ.get("LDPC_AMD_PHASE_TRACE_BUILD"):  # debug build with per-wave phase timers (tools/phase_probe.py)
+    FLAGS.append("-DLDPC_AMD_PHASE_TRACE")
 
 
 def _stale(target, deps):

@@ -355,6 +355,9 @@ void Engine::upload_plan()
     UP(vn_blocks, p.vn_blocks);
     UP(vn_slot, p.vn_slot);
     UP(cn_work, p.cn_work);
+    UP(cn_work_desc, p.cn_work_desc);
+    UP(vn_work_desc, p.vn_work_desc);
+    dev_.cn_desc_stride = p.cn_desc_stride;
     UP(vn_work, p.vn_work);
     UP(col_rank, p.col_rank);
     UP(rank_col, p.rank_col);
@@ -460,7 +463,31 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         uint32_t *redo = static_cast<uint32_t *>(redo_.reserve(4 * (n + 1)));
         check(hipMemsetAsync(redo, 0, 4, s), "redo count");
         a.redo_count = redo, a.redo_list = redo + 1;
+#ifdef LDPC_AMD_PHASE_TRACE
+        uint64_t *tr = nullptr;
+        if (std::getenv("LDPC_AMD_PHASE_TRACE")) // debug build: per-wave phase timers of the first 2048 frames -> file
+        {
+            check(hipMalloc(&tr, 2048 * 16 * 8), "trace");
+            check(hipMemset(tr, 0, 2048 * 16 * 8), "trace");
+            a.phase_trace = tr;
+        }
+#endif
         launch();
+#ifdef LDPC_AMD_PHASE_TRACE
+        if (tr)
+        {
+            std::vector<uint64_t> h(2048 * 16);
+            check(hipDeviceSynchronize(), "sync");
+            check(hipMemcpy(h.data(), tr, 2048 * 16 * 8, hipMemcpyDeviceToHost), "trace");
+            if (FILE *f = std::fopen(std::getenv("LDPC_AMD_PHASE_TRACE"), "wb"))
+            {
+                std::fwrite(h.data(), 8, h.size(), f);
+                std::fclose(f);
+            }
+            (void)hipFree(tr);
+            a.phase_trace = nullptr;
+        }
+#endif
         a.redo_count = nullptr, a.redo_list = nullptr;
         a.redo_count_in = redo, a.redo_list_in = redo + 1;
     }

@@ -39,6 +39,24 @@ namespace
 {
 
 constexpr int kThreads = kDecodeWaves * kWaveSize;
+
+// Per-wave phase timers of the likelihood-ratio loop (CN pass, wait at the vote, VN pass, wait at the second
+// barrier), compiled in only with -DLDPC_AMD_PHASE_TRACE (LDPC_AMD_PHASE_TRACE_BUILD=1 python -m libldpc_amd.build);
+// read back by tools/phase_probe.py.  They are how the lock-step pairs and the in-place work lists were found.
+#ifdef LDPC_AMD_PHASE_TRACE
+#define PHASE_TIMERS uint64_t tr_cn = 0, tr_w1 = 0, tr_vn = 0, tr_w2 = 0, tr_t = 0;
+#define PHASE_START tr_t = __builtin_amdgcn_s_memtime();
+#define PHASE_TICK(acc)                                   \
+    {                                                     \
+        const uint64_t n_ = __builtin_amdgcn_s_memtime(); \
+        acc += n_ - tr_t;                                 \
+        tr_t = n_;                                        \
+    }
+#else
+#define PHASE_TIMERS
+#define PHASE_START
+#define PHASE_TICK(acc)
+#endif
 constexpr uint8_t kErasure = 'E'; // functions.h:105
 
 // check-node update on the frame's message array: slot(j) = m[j*stride] (decoder.cpp:25-45, device_cn.hpp)
@@ -137,53 +155,68 @@ __device__ __forceinline__ uint32_t cn_block_ratio_fwd(double *msg, const CnBloc
 
 // two full blocks (64 nodes each) of the same degree at once: two independent chains per lane hide the latency of
 // the divisions and of the LDS round trip; the constant stride lets the loads pair up (ds_read2st64_b64)
-template <int D>
+template <int D0, int D1>
 __device__ __forceinline__ uint32_t cn_update_ratio2(double *m0, double *m1)
 {
-    double v0[D], v1[D];
-    uint32_t g0[D], g1[D], par0 = 0, par1 = 0;
+    double v0[D0], v1[D1];
+    uint32_t g0[D0], g1[D1], par0 = 0, par1 = 0;
 #pragma unroll
-    for (int j = 0; j < D; ++j)
+    for (int j = 0; j < D0; ++j)
     {
-        const double x0 = m0[j * kWaveSize], x1 = m1[j * kWaveSize];
-        g0[j] = hi_word(x0) & 0x80000000u, g1[j] = hi_word(x1) & 0x80000000u;
-        par0 ^= g0[j], par1 ^= g1[j];
-        v0[j] = __builtin_fabs(x0), v1[j] = __builtin_fabs(x1);
+        const double x0 = m0[j * kWaveSize];
+        g0[j] = hi_word(x0) & 0x80000000u;
+        par0 ^= g0[j];
+        v0[j] = __builtin_fabs(x0);
     }
-    cn_ratio<D>(v0);
-    cn_ratio<D>(v1);
 #pragma unroll
-    for (int j = 0; j < D; ++j)
+    for (int j = 0; j < D1; ++j)
     {
+        const double x1 = m1[j * kWaveSize];
+        g1[j] = hi_word(x1) & 0x80000000u;
+        par1 ^= g1[j];
+        v1[j] = __builtin_fabs(x1);
+    }
+    cn_ratio<D0>(v0);
+    cn_ratio<D1>(v1);
+#pragma unroll
+    for (int j = 0; j < D0; ++j)
         m0[j * kWaveSize] = with_sign(v0[j], g0[j]);
+#pragma unroll
+    for (int j = 0; j < D1; ++j)
         m1[j * kWaveSize] = with_sign(v1[j], g1[j]);
-    }
     return par0 | par1;
 }
 
 template <int MAXD>
-__device__ __forceinline__ uint32_t cn_pair_ratio(double *msg, uint32_t off0, uint32_t off1, int degree, int lane)
+__device__ __forceinline__ uint32_t cn_pair_ratio(double *msg, uint32_t off0, uint32_t off1, int deg0, int deg1, int lane)
 {
     double *m0 = msg + off0 + lane, *m1 = msg + off1 + lane;
-    switch (degree) // wave-uniform
+    if (deg0 == deg1)
     {
-    case 2: return cn_update_ratio2<2>(m0, m1);
-    case 3: return cn_update_ratio2<3>(m0, m1);
-    case 4: return cn_update_ratio2<4>(m0, m1);
-    default: break;
-    }
-    if constexpr (MAXD > 4)
-        switch (degree)
+        switch (deg0) // wave-uniform
         {
-        case 5: return cn_update_ratio2<5>(m0, m1);
-        case 6: return cn_update_ratio2<6>(m0, m1);
-        case 7: return cn_update_ratio2<7>(m0, m1);
-        case 8: return cn_update_ratio2<8>(m0, m1);
+        case 2: return cn_update_ratio2<2, 2>(m0, m1);
+        case 3: return cn_update_ratio2<3, 3>(m0, m1);
+        case 4: return cn_update_ratio2<4, 4>(m0, m1);
         default: break;
         }
-    // wider nodes: one after the other
-    return cn_block_ratio_fwd<MAXD>(msg, CnBlock{off0, kWaveSize, static_cast<uint16_t>(degree)}, lane) |
-           cn_block_ratio_fwd<MAXD>(msg, CnBlock{off1, kWaveSize, static_cast<uint16_t>(degree)}, lane);
+        if constexpr (MAXD > 4)
+            switch (deg0)
+            {
+            case 5: return cn_update_ratio2<5, 5>(m0, m1);
+            case 6: return cn_update_ratio2<6, 6>(m0, m1);
+            case 7: return cn_update_ratio2<7, 7>(m0, m1);
+            case 8: return cn_update_ratio2<8, 8>(m0, m1);
+            default: break;
+            }
+    }
+    else if (deg0 == 4 && deg1 == 3) // each wave's list is in descending degree order (plan.cpp): every separate
+        return cn_update_ratio2<4, 3>(m0, m1); // chain costs the wave an LDS + division latency (~400 cycles)
+    else if (deg0 == 3 && deg1 == 2)
+        return cn_update_ratio2<3, 2>(m0, m1);
+    // anything else: one after the other
+    return cn_block_ratio_fwd<MAXD>(msg, CnBlock{off0, kWaveSize, static_cast<uint16_t>(deg0)}, lane) |
+           cn_block_ratio_fwd<MAXD>(msg, CnBlock{off1, kWaveSize, static_cast<uint16_t>(deg1)}, lane);
 }
 
 // returns the parity (bit 31) of the hard decisions on this lane's check node
@@ -699,24 +732,28 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         // v2c messages — the syndrome of the hard decisions made by VN pass I-1; one barrier with the vote; then
         // VN pass I.  A frame that converged after VN pass I-1 (or ran out of iterations) has made one CN pass
         // too many, which nothing reads: two barriers per iteration instead of three, no hard-bit array.
+        PHASE_TIMERS
         for (;;)
         {
+            PHASE_START
             uint32_t bad = 0;
-            for (int w = 0; w < P.cn_work_stride; w += 2) // blocks two at a time where they match (plan.cpp deals
-            {                                             // each wave's blocks in degree order)
-                const uint32_t bi0 = my_cn[w];
-                if (bi0 == 0xFFFF)
+            // blocks two at a time where they match (plan.cpp deals each wave's blocks in degree order); both
+            // descriptors arrive with one scalar load (plan.cpp, cn_work_desc)
+            const auto my_desc = uniform_table(reinterpret_cast<const uint32_t *>(P.cn_work_desc + wave * P.cn_desc_stride));
+            for (int w = 0; w < P.cn_work_stride; w += 2)
+            {
+                const uint32_t d0 = my_desc[2 * w], d1 = my_desc[2 * w + 1], d2 = my_desc[2 * w + 2], d3 = my_desc[2 * w + 3];
+                const CnBlock b0{d0, static_cast<uint16_t>(d1 & 0xFFFFu), static_cast<uint16_t>(d1 >> 16)};
+                const CnBlock b1{d2, static_cast<uint16_t>(d3 & 0xFFFFu), static_cast<uint16_t>(d3 >> 16)};
+                if (b0.count == 0)
                     break;
-                const CnBlock b0 = load_block2(P.cn_blocks, bi0);
-                const uint32_t bi1 = w + 1 < P.cn_work_stride ? my_cn[w + 1] : 0xFFFFu;
-                if (bi1 == 0xFFFF)
+                if (b1.count == 0)
                 {
                     bad |= cn_block_ratio<MAXD>(msg, b0, lane);
                     break;
                 }
-                const CnBlock b1 = load_block2(P.cn_blocks, bi1);
-                if (b0.degree == b1.degree && b0.count == kWaveSize && b1.count == kWaveSize)
-                    bad |= cn_pair_ratio<MAXD>(msg, b0.off, b1.off, b0.degree, lane);
+                if (b0.count == kWaveSize && b1.count == kWaveSize)
+                    bad |= cn_pair_ratio<MAXD>(msg, b0.off, b1.off, b0.degree, b1.degree, lane);
                 else
                     bad |= cn_block_ratio<MAXD>(msg, b0, lane) | cn_block_ratio<MAXD>(msg, b1, lane);
             }
@@ -724,11 +761,20 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             const int wave_vote = (__ballot(bad != 0) != 0) | ((__ballot(DM_RATIO_ESCAPED(escaped)) != 0) << 1);
             if (lane == 0)
                 votes[ph][wave] = wave_vote;
+            PHASE_TICK(tr_cn)
             __syncthreads();
+            PHASE_TICK(tr_w1)
             int any = 0;
 #pragma unroll
             for (int w = 0; w < kDecodeWaves; ++w)
                 any |= votes[ph][w];
+#ifdef LDPC_AMD_PHASE_TRACE
+            if (((I > 0 && !(any & 1)) || I == a.iterations) && a.phase_trace && frame < 2048 && lane == 0)
+            {
+                uint64_t *o = a.phase_trace + (frame * 4 + wave) * 4;
+                o[0] = tr_cn, o[1] = tr_w1, o[2] = tr_vn, o[3] = tr_w2;
+            }
+#endif
             if (any & 2) // checked before the syndrome: an escaped frame's hard decisions mean nothing
             {
                 if (tid == 0)
@@ -765,22 +811,27 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                         prod = vn_block_ratio(msg, P.vn_slot + b.idx_off + lane, b.count, b.degree, lam, escaped);
                     put_llr(b, prod);
                 };
+                // this wave's block descriptors come straight from its work list (plan.cpp, vn_work_desc): one scalar
+                // load each, none of them dependent on another
+                const auto my_vdesc = uniform_table(P.vn_work_desc + wave * (P.vn_work_stride + 1) * 4);
+                auto vdesc = [&](int w) {
+                    const uint32_t d0 = my_vdesc[4 * w], d1 = my_vdesc[4 * w + 1], d2 = my_vdesc[4 * w + 2];
+                    return VnBlock{d0, d1, static_cast<uint16_t>(d2 & 0xFFFFu), static_cast<uint16_t>(d2 >> 16)};
+                };
 #pragma unroll
                 for (int w = 0; w < kMaxVnBlocksInRegs; w += 2) // full low-degree blocks two at a time in lock step
                 {                                               // (plan.cpp deals each wave's blocks in degree order)
                     if (w >= P.vn_work_stride)
                         break;
-                    const uint32_t bi0 = my_vn[w];
-                    if (bi0 == 0xFFFF)
+                    const VnBlock b0 = vdesc(w);
+                    if (b0.count == 0)
                         break;
-                    const VnBlock b0 = load_block3(P.vn_blocks, bi0);
-                    const uint32_t bi1 = w + 1 < P.vn_work_stride ? my_vn[w + 1] : 0xFFFFu;
-                    if (bi1 == 0xFFFF)
+                    const VnBlock b1 = vdesc(w + 1 < P.vn_work_stride ? w + 1 : P.vn_work_stride); // (row ends in a "none")
+                    if (b1.count == 0)
                     {
                         one(b0, w, my_idx[w], my_llr[w]);
                         break;
                     }
-                    const VnBlock b1 = load_block3(P.vn_blocks, bi1);
                     if (b0.degree == b1.degree && b0.degree >= 1 && b0.degree <= 2 && b0.count == kWaveSize &&
                         b1.count == kWaveSize)
                     {
@@ -807,7 +858,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     if constexpr (WANT_LLR)
                         out_llr[P.rank_col[b.first + lane]] = 0.0 - dm_log(prod);
                 });
+            PHASE_TICK(tr_vn)
             __syncthreads();
+            PHASE_TICK(tr_w2)
             ++I;
         }
     }

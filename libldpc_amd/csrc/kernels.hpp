@@ -20,6 +20,9 @@ struct DevPlan
     const uint32_t *vn_slot;
     const uint32_t *cn_work;
     const uint32_t *vn_work;
+    const CnBlock *cn_work_desc; // [kDecodeWaves][cn_desc_stride], count 0 = none
+    int cn_desc_stride;
+    const uint32_t *vn_work_desc; // [kDecodeWaves][vn_work_stride + 1][4], count 0 = none
     const uint32_t *col_rank;
     const uint32_t *rank_col;
     const uint32_t *tx_rank;
@@ -75,6 +78,7 @@ struct DecodeArgs
     uint32_t *redo_count;
     const uint32_t *redo_list_in;
     const uint32_t *redo_count_in;
+    uint64_t *phase_trace; // debug builds with -DLDPC_AMD_PHASE_TRACE only: [2048 frames][4 waves][4 timers]
 };
 
 // device copy of RegPlan (register-resident decoder, kernels_reg.hip)

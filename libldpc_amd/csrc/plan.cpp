@@ -61,7 +61,11 @@ Plan build_plan(const LdpcCode &code)
                 p.edge_slot[H.redge[H.rptr[rows[i + l]] + k]] = slot + k * (j - i) + l;
         slot += static_cast<uint32_t>(d) * (j - i);
         p.cn_blocks.push_back(b);
-        cn_cost.push_back(std::max(1, 3 * (d - 2)) * 8 + d);
+        // relative issue cost of one block: d loads/stores + 3(d-2) box-pluses in the LLR-domain form, d divisions
+        // (+ the partial results) in the likelihood-ratio form: both close to 10 d + 15 (d - 2) (measured with per-wave
+        // phase timers on h.txt: with the old 8*3(d-2)+d weights the waves holding four degree-3 blocks and one
+        // degree-4 block ran 10 % longer than those holding two of each)
+        cn_cost.push_back(10 * d + 15 * (d - 2));
         i = j;
     }
 
@@ -101,6 +105,21 @@ Plan build_plan(const LdpcCode &code)
 
     deal(cn_cost, p.cn_work, p.cn_work_stride);
     deal(vn_cost, p.vn_work, p.vn_work_stride);
+    p.vn_work_desc.assign(static_cast<size_t>(kDecodeWaves) * (p.vn_work_stride + 1) * 4, 0);
+    for (int w = 0; w < kDecodeWaves; ++w)
+        for (int i = 0; i < p.vn_work_stride; ++i)
+            if (uint32_t b = p.vn_work[static_cast<size_t>(w) * p.vn_work_stride + i]; b != 0xFFFF)
+            {
+                uint32_t *d = &p.vn_work_desc[(static_cast<size_t>(w) * (p.vn_work_stride + 1) + i) * 4];
+                const VnBlock &vb = p.vn_blocks[b];
+                d[0] = vb.idx_off, d[1] = vb.first, d[2] = vb.count | (static_cast<uint32_t>(vb.degree) << 16);
+            }
+    p.cn_desc_stride = (p.cn_work_stride + 1) / 2 * 2 + 2;
+    p.cn_work_desc.assign(static_cast<size_t>(kDecodeWaves) * p.cn_desc_stride, CnBlock{0, 0, 0});
+    for (int w = 0; w < kDecodeWaves; ++w)
+        for (int i = 0; i < p.cn_work_stride; ++i)
+            if (uint32_t b = p.cn_work[static_cast<size_t>(w) * p.cn_work_stride + i]; b != 0xFFFF)
+                p.cn_work_desc[static_cast<size_t>(w) * p.cn_desc_stride + i] = p.cn_blocks[b];
 
     // ---- channel-side tables ----
     p.rank_kind.assign(p.nc, 0);

@@ -58,6 +58,12 @@ struct Plan
     std::vector<uint32_t> cn_work;   // [kDecodeWaves][cn_work_stride] block ids, 0xFFFF = none
     std::vector<uint32_t> vn_work;   // [kDecodeWaves][vn_work_stride]
     int cn_work_stride = 0, vn_work_stride = 0;
+    // the same work lists with the descriptors in place of the block ids (count 0 = none; cn_work_desc rows are
+    // padded to an even number of entries plus two): a wave reads the two blocks it handles together with ONE
+    // scalar load instead of two dependent ones
+    std::vector<CnBlock> cn_work_desc; // [kDecodeWaves][cn_desc_stride]
+    int cn_desc_stride = 0;
+    std::vector<uint32_t> vn_work_desc; // [kDecodeWaves][vn_work_stride + 1][4]: idx_off, first, count | degree << 16, 0
     std::vector<uint32_t> col_rank;  // column -> VN rank
     std::vector<uint32_t> rank_col;  // VN rank -> column
     std::vector<uint32_t> tx_rank;   // transmitted index i -> rank of bit_pos[i]

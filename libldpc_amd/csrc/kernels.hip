@@ -625,7 +625,6 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     }
 
     const auto my_vn = uniform_table(P.vn_work + wave * P.vn_work_stride);
-    const auto my_cn = uniform_table(P.cn_work + wave * P.cn_work_stride);
     uint32_t escaped = 0; // RATIO: running maximum of dm_ratio_key over the frame's checked values (detmath.h)
     if constexpr (RATIO && LLR_MODE != kLlrRegs)
     {
@@ -684,6 +683,18 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         }
         __syncthreads(); // every lane holds its LLRs: the message array may now be written
     }
+    // The work lists of this wave with the block descriptors in place (plan.cpp, cn_work_desc / vn_work_desc): one
+    // scalar load per block, none dependent on another (block id -> descriptor costs a second, dependent one).
+    const auto my_vdesc = uniform_table(P.vn_work_desc + wave * (P.vn_work_stride + 1) * 4);
+    const auto my_cdesc = uniform_table(reinterpret_cast<const uint32_t *>(P.cn_work_desc + wave * P.cn_desc_stride));
+    auto vn_desc = [&](int w) { // count 0 = none (every row ends in one)
+        const uint32_t d0 = my_vdesc[4 * w], d1 = my_vdesc[4 * w + 1], d2 = my_vdesc[4 * w + 2];
+        return VnBlock{d0, d1, static_cast<uint16_t>(d2 & 0xFFFFu), static_cast<uint16_t>(d2 >> 16)};
+    };
+    auto cn_desc = [&](int w) { // count 0 = none (every row ends in two)
+        const uint32_t d0 = my_cdesc[2 * w], d1 = my_cdesc[2 * w + 1];
+        return CnBlock{d0, static_cast<uint16_t>(d1 & 0xFFFFu), static_cast<uint16_t>(d1 >> 16)};
+    };
     // the w-th VN block of this wave: body(block, input LLR of this lane's node)
     auto for_my_vn_blocks = [&](auto &&body) {
         if constexpr (LLR_MODE == kLlrRegs)
@@ -693,10 +704,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             {
                 if (w >= P.vn_work_stride)
                     break;
-                const uint32_t bi = my_vn[w];
-                if (bi == 0xFFFF)
+                const VnBlock b = vn_desc(w);
+                if (b.count == 0)
                     break;
-                const VnBlock b = load_block3(P.vn_blocks, bi);
                 if (lane < b.count)
                     body(b, my_llr[w]);
             }
@@ -705,10 +715,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         {
             for (int w = 0; w < P.vn_work_stride; ++w)
             {
-                const uint32_t bi = my_vn[w];
-                if (bi == 0xFFFF)
+                const VnBlock b = vn_desc(w);
+                if (b.count == 0)
                     break;
-                const VnBlock b = load_block3(P.vn_blocks, bi);
                 if (lane < b.count)
                     body(b, llr[b.first + lane]);
             }
@@ -739,10 +748,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             uint32_t bad = 0;
             // blocks two at a time where they match (plan.cpp deals each wave's blocks in degree order); both
             // descriptors arrive with one scalar load (plan.cpp, cn_work_desc)
-            const auto my_desc = uniform_table(reinterpret_cast<const uint32_t *>(P.cn_work_desc + wave * P.cn_desc_stride));
             for (int w = 0; w < P.cn_work_stride; w += 2)
             {
-                const uint32_t d0 = my_desc[2 * w], d1 = my_desc[2 * w + 1], d2 = my_desc[2 * w + 2], d3 = my_desc[2 * w + 3];
+                const uint32_t d0 = my_cdesc[2 * w], d1 = my_cdesc[2 * w + 1], d2 = my_cdesc[2 * w + 2], d3 = my_cdesc[2 * w + 3];
                 const CnBlock b0{d0, static_cast<uint16_t>(d1 & 0xFFFFu), static_cast<uint16_t>(d1 >> 16)};
                 const CnBlock b1{d2, static_cast<uint16_t>(d3 & 0xFFFFu), static_cast<uint16_t>(d3 >> 16)};
                 if (b0.count == 0)
@@ -813,7 +821,6 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                 };
                 // this wave's block descriptors come straight from its work list (plan.cpp, vn_work_desc): one scalar
                 // load each, none of them dependent on another
-                const auto my_vdesc = uniform_table(P.vn_work_desc + wave * (P.vn_work_stride + 1) * 4);
                 auto vdesc = [&](int w) {
                     const uint32_t d0 = my_vdesc[4 * w], d1 = my_vdesc[4 * w + 1], d2 = my_vdesc[4 * w + 2];
                     return VnBlock{d0, d1, static_cast<uint16_t>(d2 & 0xFFFFu), static_cast<uint16_t>(d2 >> 16)};
@@ -871,10 +878,10 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             // ---- CN pass: decoder.cpp:25-45 ----
             for (int w = 0; w < P.cn_work_stride; ++w)
             {
-                const uint32_t bi = my_cn[w];
-                if (bi == 0xFFFF)
+                const CnBlock b = cn_desc(w);
+                if (b.count == 0)
                     break;
-                cn_block<MINSUM, MAXD>(msg, load_block2(P.cn_blocks, bi), lane);
+                cn_block<MINSUM, MAXD>(msg, b, lane);
             }
             __syncthreads();
 
@@ -892,10 +899,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                 int bad = 0;
                 for (int w = 0; w < P.cn_work_stride; ++w)
                 {
-                    const uint32_t bi = my_cn[w];
-                    if (bi == 0xFFFF)
+                    const CnBlock b = cn_desc(w);
+                    if (b.count == 0)
                         break;
-                    const CnBlock b = load_block2(P.cn_blocks, bi);
                     if (lane < b.count)
                     {
                         int par = 0;

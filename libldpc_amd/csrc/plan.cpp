@@ -2,6 +2,8 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <stdexcept>
 
@@ -81,6 +83,9 @@ Plan build_plan(const LdpcCode &code)
         p.col_rank[cols[r]] = static_cast<uint32_t>(r);
     }
     std::vector<int> vn_cost;
+    int vn_cost_a = 2, vn_cost_b = 2; // per-edge and per-block share of a block's cost (LDPC_AMD_VN_COST=a,b: experiments)
+    if (const char *e = std::getenv("LDPC_AMD_VN_COST"))
+        std::sscanf(e, "%d,%d", &vn_cost_a, &vn_cost_b);
     for (int i = 0; i < p.nc;)
     {
         int d = cdeg(cols[i]), j = i;
@@ -92,7 +97,7 @@ Plan build_plan(const LdpcCode &code)
             for (int l = 0; l < j - i; ++l)
                 p.vn_slot.push_back(p.edge_slot[H.cedge[H.cptr[cols[i + l]] + k]]);
         p.vn_blocks.push_back(b);
-        vn_cost.push_back(2 * d + 2);
+        vn_cost.push_back(vn_cost_a * d + vn_cost_b);
         i = j;
     }
     p.has_isolated_vn = p.nc > 0 && cdeg(cols[p.nc - 1]) == 0; // sorted by degree, descending

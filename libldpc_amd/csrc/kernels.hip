@@ -116,6 +116,64 @@ __device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane)
     }
 }
 
+// two full blocks (64 nodes each) at once: one LDS round trip for both (min-sum is bound by exactly that latency)
+template <int D0, int D1, bool MINSUM>
+__device__ __forceinline__ void cn_update2(double *m0, double *m1)
+{
+    double v0[D0], v1[D1];
+#pragma unroll
+    for (int j = 0; j < D0; ++j)
+        v0[j] = m0[j * kWaveSize];
+#pragma unroll
+    for (int j = 0; j < D1; ++j)
+        v1[j] = m1[j * kWaveSize];
+    cn_core<D0, MINSUM>(v0);
+    cn_core<D1, MINSUM>(v1);
+#pragma unroll
+    for (int j = 0; j < D0; ++j)
+        m0[j * kWaveSize] = v0[j];
+#pragma unroll
+    for (int j = 0; j < D1; ++j)
+        m1[j * kWaveSize] = v1[j];
+}
+
+// returns false when the two degrees have no paired form (the caller then takes the blocks one after the other)
+template <bool MINSUM, int MAXD>
+__device__ __forceinline__ bool cn_pair(double *msg, uint32_t off0, uint32_t off1, int deg0, int deg1, int lane)
+{
+    double *m0 = msg + off0 + lane, *m1 = msg + off1 + lane;
+    if (deg0 == deg1)
+    {
+        switch (deg0) // wave-uniform
+        {
+        case 2: cn_update2<2, 2, MINSUM>(m0, m1); return true;
+        case 3: cn_update2<3, 3, MINSUM>(m0, m1); return true;
+        case 4: cn_update2<4, 4, MINSUM>(m0, m1); return true;
+        default: break;
+        }
+        if constexpr (MAXD > 4)
+            switch (deg0)
+            {
+            case 5: cn_update2<5, 5, MINSUM>(m0, m1); return true;
+            case 6: cn_update2<6, 6, MINSUM>(m0, m1); return true;
+            case 7: cn_update2<7, 7, MINSUM>(m0, m1); return true;
+            case 8: cn_update2<8, 8, MINSUM>(m0, m1); return true;
+            default: break;
+            }
+    }
+    else if (deg0 == 4 && deg1 == 3) // each wave's list is in descending degree order (plan.cpp)
+    {
+        cn_update2<4, 3, MINSUM>(m0, m1);
+        return true;
+    }
+    else if (deg0 == 3 && deg1 == 2)
+    {
+        cn_update2<3, 2, MINSUM>(m0, m1);
+        return true;
+    }
+    return false;
+}
+
 // ---- likelihood-ratio form (RATIO instantiations): all messages are positive, so the sign bit of a message slot
 // is free and carries the hard decision of the edge's variable node (set by the VN pass, preserved by the CN
 // pass).  The CN pass therefore sees the syndrome of the previous iteration for free. ----
@@ -513,6 +571,34 @@ __device__ __forceinline__ double vn_update_llr(double *msg, uint8_t *hb, const 
     return out;
 }
 
+// two nodes (of two full blocks) of the same degree DV <= 2 in lock step
+template <int DV>
+__device__ __forceinline__ void vn_update_llr2(double *msg, uint8_t *hb, const uint32_t *idx0, const uint32_t *idx1, double L0,
+                                               double L1, double &out0, double &out1)
+{
+    uint32_t s0[DV], s1[DV];
+    double c0[DV], c1[DV];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        s0[p] = idx0[p * kWaveSize], s1[p] = idx1[p * kWaveSize];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        c0[p] = msg[s0[p]], c1[p] = msg[s1[p]];
+    out0 = L0, out1 = L1;
+#pragma unroll
+    for (int p = 0; p < DV; ++p) // sequential sum in column file order
+        out0 += c0[p], out1 += c1[p];
+    const uint8_t bit0 = out0 <= 0, bit1 = out1 <= 0;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+    {
+        msg[s0[p]] = out0 - c0[p];
+        msg[s1[p]] = out1 - c1[p];
+        hb[s0[p]] = bit0;
+        hb[s1[p]] = bit1;
+    }
+}
+
 __device__ __forceinline__ double vn_block_llr(double *msg, uint8_t *hb, const uint32_t *idx, int count, int degree, double L)
 {
     switch (degree) // wave-uniform
@@ -876,21 +962,80 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         while (I < a.iterations)
         {
             // ---- CN pass: decoder.cpp:25-45 ----
-            for (int w = 0; w < P.cn_work_stride; ++w)
+            if constexpr (MINSUM) // latency-bound: full blocks two at a time (one LDS round trip for both)
             {
-                const CnBlock b = cn_desc(w);
-                if (b.count == 0)
-                    break;
-                cn_block<MINSUM, MAXD>(msg, b, lane);
+                for (int w = 0; w < P.cn_work_stride; w += 2)
+                {
+                    const CnBlock b0 = cn_desc(w), b1 = cn_desc(w + 1);
+                    if (b0.count == 0)
+                        break;
+                    if (b1.count == kWaveSize && b0.count == kWaveSize &&
+                        cn_pair<MINSUM, MAXD>(msg, b0.off, b1.off, b0.degree, b1.degree, lane))
+                        continue;
+                    cn_block<MINSUM, MAXD>(msg, b0, lane);
+                    if (b1.count == 0)
+                        break;
+                    cn_block<MINSUM, MAXD>(msg, b1, lane);
+                }
             }
+            else
+                for (int w = 0; w < P.cn_work_stride; ++w)
+                {
+                    const CnBlock b = cn_desc(w);
+                    if (b.count == 0)
+                        break;
+                    cn_block<MINSUM, MAXD>(msg, b, lane);
+                }
             __syncthreads();
 
             // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
-            for_my_vn_blocks([&](const VnBlock &b, double L) {
+            auto vn_one = [&](const VnBlock &b, double L) {
+                if (lane >= b.count)
+                    return;
                 const double out = vn_block_llr(msg, hb, P.vn_slot + b.idx_off + lane, b.count, b.degree, L);
                 if constexpr (WANT_LLR)
                     out_llr[P.rank_col[b.first + lane]] = out;
-            });
+            };
+            if constexpr (MINSUM && LLR_MODE == kLlrRegs)
+            {
+#pragma unroll
+                for (int w = 0; w < kMaxVnBlocksInRegs; w += 2) // full low-degree blocks two at a time in lock step
+                {
+                    if (w >= P.vn_work_stride)
+                        break;
+                    const VnBlock b0 = vn_desc(w);
+                    if (b0.count == 0)
+                        break;
+                    const VnBlock b1 = vn_desc(w + 1 < P.vn_work_stride ? w + 1 : P.vn_work_stride);
+                    if (b1.count == 0)
+                    {
+                        vn_one(b0, my_llr[w]);
+                        break;
+                    }
+                    if (b0.degree == b1.degree && b0.degree >= 1 && b0.degree <= 2 && b0.count == kWaveSize &&
+                        b1.count == kWaveSize)
+                    {
+                        const uint32_t *i0 = P.vn_slot + b0.idx_off + lane, *i1 = P.vn_slot + b1.idx_off + lane;
+                        double o0, o1;
+                        if (b0.degree == 1)
+                            vn_update_llr2<1>(msg, hb, i0, i1, my_llr[w], my_llr[w + 1], o0, o1);
+                        else
+                            vn_update_llr2<2>(msg, hb, i0, i1, my_llr[w], my_llr[w + 1], o0, o1);
+                        if constexpr (WANT_LLR)
+                        {
+                            out_llr[P.rank_col[b0.first + lane]] = o0;
+                            out_llr[P.rank_col[b1.first + lane]] = o1;
+                        }
+                    }
+                    else
+                    {
+                        vn_one(b0, my_llr[w]);
+                        vn_one(b1, my_llr[w + 1]);
+                    }
+                }
+            }
+            else
+                for_my_vn_blocks([&](const VnBlock &b, double L) { vn_one(b, L); });
             __syncthreads();
 
             // ---- syndrome early termination: decoder.cpp:66-72, decoder.h:47-64 ----

@@ -133,9 +133,13 @@ def main():
     if first:
         dec.stream_skip(first, stream)
 
+    c = torch.zeros(5, dtype=torch.int64, device=dev)
+
     def step():
         dec.stream_decode(B, early_term=early, iterations=ITERS, decoding=args.decoding, want=(), out=out, stream=stream)
-        c = shard.counters_from_outputs(torch, iters_d, be_d, ITERS, early)
+        # {frames, fec, bec, iters, converged} of the batch, summed by the library in one launch on the same stream
+        # (shard.counters_from_outputs is the torch spelling of the same five sums, used by the tests)
+        dec.batch_counters(iters_d.data_ptr(), be_d.data_ptr(), B, ITERS, early, c.data_ptr(), stream)
         if dist is not None and backend != "nccl":
             return shard.reduce_counters(c.cpu(), dist).to(dev)
         return shard.reduce_counters(c, dist)  # the one collective of the path: 5 x int64 over xGMI

@@ -123,6 +123,12 @@ int ldpc_hip_stream_skip(ldpc_hip_ctx *ctx, uint64_t n, void *hip_stream);
 /* channel + LLR init + decode of the next n frames of the stream, fused in one launch */
 int ldpc_hip_stream_decode(ldpc_hip_ctx *ctx, decoder_param dec, uint64_t n, const ldpc_hip_out *out,
                            void *hip_stream);
+/* the counters ldpc_sim::start accumulates per frame (ldpcsim.cpp:175-200), summed over a batch on the device:
+   counters[0..4] = {frames, frame errors (bit_errors > 0), bit errors, iterations, frames that stopped early
+   (iters < max_iters; 0 unless early_term)}.  iters / bit_errors / counters are DEVICE pointers (the outputs of a
+   decode call on the same stream); one launch, ordered on hip_stream.  A multi-GPU run all-reduces these five. */
+int ldpc_hip_batch_counters(ldpc_hip_ctx *ctx, const uint32_t *iters, const uint32_t *bit_errors, uint64_t n,
+                            uint32_t max_iters, int early_term, int64_t *counters, void *hip_stream);
 /* frames consumed / raw 64-bit draws consumed since ldpc_hip_stream_begin */
 uint64_t ldpc_hip_stream_frame(const ldpc_hip_ctx *ctx);
 uint64_t ldpc_hip_stream_raw_draws(const ldpc_hip_ctx *ctx);

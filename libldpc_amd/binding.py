@@ -69,6 +69,8 @@ def load_library(path=LIB_PATH):
     L.ldpc_hip_stream_raw_draws.argtypes = [vp]
     L.ldpc_hip_synchronize.restype = i32
     L.ldpc_hip_synchronize.argtypes = [vp, vp]
+    L.ldpc_hip_batch_counters.restype = i32
+    L.ldpc_hip_batch_counters.argtypes = [vp, vp, vp, u64, ct.c_uint32, i32, vp, vp]
     L.ldpc_hip_selftest_division.restype = i32
     L.ldpc_hip_selftest_division.argtypes = [vp, u64, u64, vp]
     L.ldpc_hip_mt64.restype = i32
@@ -183,6 +185,12 @@ class HipDecoder:
 
     def last_ms(self, which=0):
         return float(self.lib.ldpc_hip_last_ms(self.ctx, which))
+
+    def batch_counters(self, iters_ptr, bit_errors_ptr, n, max_iters, early_term, counters_ptr, stream=None):
+        """{frames, frame errors, bit errors, iterations, early stops} of a batch, summed on the device (all three
+        arguments are device pointers, e.g. tensor.data_ptr()); one launch on `stream`."""
+        self._check(self.lib.ldpc_hip_batch_counters(self.ctx, iters_ptr, bit_errors_ptr, int(n), int(max_iters),
+                                                     int(bool(early_term)), counters_ptr, stream), "ldpc_hip_batch_counters")
 
     def selftest_division(self, n, seed=1):
         """Pairs (of n) on which the kernels' division sequence and the IEEE division disagree (expected 0)."""

@@ -310,6 +310,22 @@ int ldpc_hip_mt64(ldpc_hip_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, 
     });
 }
 
+int ldpc_hip_batch_counters(ldpc_hip_ctx *ctx, const uint32_t *iters, const uint32_t *bit_errors, uint64_t n,
+                            uint32_t max_iters, int early_term, int64_t *counters, void *hip_stream)
+{
+    return guarded([&] {
+        if (ldpc_hip_device_count() <= ctx->eng->device())
+            throw std::runtime_error("no usable HIP device (MI355X required)");
+        if (hipSetDevice(ctx->eng->device()) != hipSuccess)
+            throw std::runtime_error("hipSetDevice failed");
+        if (!iters || !bit_errors || !counters)
+            throw std::runtime_error("ldpc_hip_batch_counters: null pointer");
+        if (ldpc_amd::launch_batch_counters(iters, bit_errors, n, max_iters, early_term,
+                                            reinterpret_cast<long long *>(counters), hip_stream) != hipSuccess)
+            throw std::runtime_error("ldpc_hip_batch_counters: launch failed");
+    });
+}
+
 int ldpc_hip_selftest_division(ldpc_hip_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *mismatches)
 {
     return guarded([&] {

@@ -1432,6 +1432,40 @@ __global__ __launch_bounds__(256) void encode_cw_kernel(const EncodeArgs a, uint
     }
 }
 
+// one workgroup sums the per-frame outputs of a batch (64 K frames: 64 per thread) into the five counters of the
+// simulation loop (ldpcsim.cpp:175-200): frames, frame errors, bit errors, iterations, early stops
+__global__ __launch_bounds__(1024) void batch_counters_kernel(const uint32_t *iters, const uint32_t *bit_errors, uint64_t n,
+                                                              uint32_t max_iters, int early_term, long long *counters)
+{
+    __shared__ long long part[4][16];
+    long long fe = 0, be = 0, it = 0, es = 0;
+    for (uint64_t i = threadIdx.x; i < n; i += 1024)
+    {
+        const uint32_t b = bit_errors[i], t = iters[i];
+        fe += b > 0, be += b, it += t, es += early_term && t < max_iters;
+    }
+    auto wave_total = [](long long v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    fe = wave_total(fe), be = wave_total(be), it = wave_total(it), es = wave_total(es);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+        part[0][wave] = fe, part[1][wave] = be, part[2][wave] = it, part[3][wave] = es;
+    __syncthreads();
+    if (threadIdx.x < 4)
+    {
+        long long s = 0;
+        for (int w = 0; w < 16; ++w)
+            s += part[threadIdx.x][w];
+        counters[1 + threadIdx.x] = s;
+    }
+    if (threadIdx.x == 4)
+        counters[0] = static_cast<long long>(n);
+}
+
 // operands a = 2^ea * ma, b = 2^eb * mb with ea, eb in [-500, 500] and random mantissas: a, b, a/b inside 2^-+1001
 __global__ __launch_bounds__(256) void division_selftest_kernel(uint64_t n, uint64_t seed, unsigned long long *mismatches)
 {
@@ -1530,6 +1564,14 @@ int launch_decode_mem(const DecodeArgs &a, bool min_sum, int max_cn_degree, uint
     if (max_cn_degree <= 16)
         return launch_decode<false, 16, kLlrMem>(a, min_sum, occupancy_lds, stream);
     return hipErrorInvalidValue;
+}
+
+int launch_batch_counters(const uint32_t *iters, const uint32_t *bit_errors, uint64_t n, uint32_t max_iters, int early_term,
+                          long long *counters, void *stream)
+{
+    hipLaunchKernelGGL(batch_counters_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), iters, bit_errors, n,
+                       max_iters, early_term, counters);
+    return hipGetLastError();
 }
 
 int launch_division_selftest(uint64_t n, uint64_t seed, unsigned long long *mismatches, void *stream)

@@ -171,6 +171,10 @@ struct EncodeArgs
 };
 int launch_encode(const EncodeArgs &a, void *stream);
 
+// {frames, frame errors, bit errors, iterations, early stops} of a batch (all device pointers), one launch
+int launch_batch_counters(const uint32_t *iters, const uint32_t *bit_errors, uint64_t n, uint32_t max_iters, int early_term,
+                          long long *counters, void *stream);
+
 // dm_ratio_div vs the IEEE division on n pseudo-random operand pairs; *mismatches (device, zeroed by the caller)
 int launch_division_selftest(uint64_t n, uint64_t seed, unsigned long long *mismatches, void *stream);
 

@@ -350,3 +350,23 @@ def test_device_encoded_codewords_have_zero_syndrome(decg):
     assert cw.shape == (40, code.nc) and cw.any() and len({c.tobytes() for c in cw}) > 30
     for c in cw:
         assert not code.syndrome(c).any()
+
+
+def test_batch_counters_on_device(dec):
+    """ldpc_hip_batch_counters: the five sums of a batch in one launch == the torch spelling in shard.py."""
+    import torch
+    from libldpc_amd import shard
+    n = 5000
+    dev = torch.device("cuda", 0)
+    it = torch.zeros(n, dtype=torch.int32, device=dev)
+    be = torch.zeros(n, dtype=torch.int32, device=dev)
+    c = torch.full((5,), -1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for early, iters, x in ((True, 50, -4.3), (False, 6, -4.0)):
+        dec.stream_begin("AWGN", 2, x)
+        dec.stream_decode(n, early_term=early, iterations=iters, want=(), out={"iters": it, "bit_errors": be}, stream=stream)
+        dec.batch_counters(it.data_ptr(), be.data_ptr(), n, iters, early, c.data_ptr(), stream)
+        ref = shard.counters_from_outputs(torch, it, be, iters, early)
+        torch.cuda.synchronize()
+        assert torch.equal(c, ref), (c, ref)
+        assert int(c[0]) == n and int(c[1]) > 0

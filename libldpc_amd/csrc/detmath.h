@@ -208,6 +208,42 @@ DM_FN double dm_boxplus_exp(double t)
 #endif
 }
 
+/* e^x for |x| <= 700 (arguments beyond are clamped), branch-free: the same reduction, polynomial and scaling as
+   dm_exp — identical bits wherever both are defined — without its special cases and its 64-bit integer detour.
+   Used for lambda(L_ch) = e^-L_ch at the head of the likelihood-ratio form (|L_ch| <= 166 there, or the frame has
+   already escaped). */
+DM_FN double dm_exp_clamped(double x)
+{
+    x = __builtin_fmin(__builtin_fmax(x, -700.0), 700.0);
+    double z = x * DM_INV_LN2;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double kd = __builtin_rint(z); /* v_rndne_f64: same value as the add/subtract form below */
+#else
+    double kd = (z + DM_RND_MAGIC) - DM_RND_MAGIC;
+#endif
+    double r = DM_FMA(kd, -DM_LN2_HI, x);
+    r = DM_FMA(kd, -DM_LN2_LO, r);
+    double g = DM_EXP_G9;
+    g = DM_FMA(g, r, DM_EXP_G8);
+    g = DM_FMA(g, r, DM_EXP_G7);
+    g = DM_FMA(g, r, DM_EXP_G6);
+    g = DM_FMA(g, r, DM_EXP_G5);
+    g = DM_FMA(g, r, DM_EXP_G4);
+    g = DM_FMA(g, r, DM_EXP_G3);
+    g = DM_FMA(g, r, DM_EXP_G2);
+    g = DM_FMA(g, r, DM_EXP_G1);
+    g = DM_FMA(g, r, DM_EXP_G0);
+    double r2 = r * r;
+    double s = DM_FMA(r2, g, r);
+    double p = 1.0 + s;
+    int k = (int)kd; /* |k| <= 1010: the scale factor is a normal number */
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_ldexp(p, k); /* v_ldexp_f64: exact scaling, same value as the multiply below */
+#else
+    return p * dm_from_bits((uint64_t)(k + 1023) << 52);
+#endif
+}
+
 DM_FN double dm_boxplus_log(double q)
 {
     uint64_t ix = dm_bits(q);

@@ -48,7 +48,11 @@ __device__ __forceinline__ void channel_init(const DecodeArgs &a, uint64_t frame
             for (uint64_t q = q_lo + tid; q <= q_hi; q += kThreads)
             {
                 // the noise-stream kernels (polar_compact_kernel) already turned the accepted trial into its normals
-                const ulonglong2 pp = *reinterpret_cast<const ulonglong2 *>(a.pairs + 2 * (q - a.pair_base));
+                // streamed once: non-temporal, so that the 8 KB of a frame do not push the slot tables — which every
+                // frame that starts on this CU reads — out of the CU's 32 KB vector cache
+                const uint64_t *pq = a.pairs + 2 * (q - a.pair_base);
+                ulonglong2 pp;
+                pp.x = __builtin_nontemporal_load(pq), pp.y = __builtin_nontemporal_load(pq + 1);
                 const double nrm[2] = {dm_from_bits(pp.x), dm_from_bits(pp.y)};
 #pragma unroll
                 for (int k = 0; k < 2; ++k)

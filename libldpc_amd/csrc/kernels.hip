@@ -721,7 +721,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                 const double L = llr[r];
                 if (!(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT))
                     escaped = ~0u;
-                llr[r] = dm_exp(0.0 - L);
+                llr[r] = dm_exp_clamped(0.0 - L);
             }
         __syncthreads();
     }
@@ -751,7 +751,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                         {
                             if (!(__builtin_fabs(my_llr[w]) <= DM_RATIO_LLR_LIMIT))
                                 escaped = ~0u;
-                            my_llr[w] = dm_exp(0.0 - my_llr[w]);
+                            my_llr[w] = dm_exp_clamped(0.0 - my_llr[w]);
                             const uint32_t *idx = P.vn_slot + b.idx_off + lane; // LDS-resident: every slot < 2^16
                             if (b.degree >= 1 && b.degree <= 2)
                                 my_idx[w] = idx[0] | (idx[(b.degree - 1) * b.count] << 16);

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
                 const double L = llr[r];
                 if (!(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT))
                     escaped = ~0u;
-                llr[r] = dm_exp(0.0 - L);
+                llr[r] = dm_exp_clamped(0.0 - L);
             }
         __syncthreads();
     }

@@ -481,7 +481,7 @@ static int dec_decode_ratio(dec_t *d)
             continue; /* isolated variable node: its LLR multiplies nothing */
         double L = d->llr_in[i];
         escaped |= !(fabs(L) <= DM_RATIO_LLR_LIMIT);
-        lam[i] = dm_exp(0.0 - L);
+        lam[i] = dm_exp_clamped(0.0 - L);
         double v0 = 1.0 / lam[i];
         for (int p = H->cptr[i]; p < H->cptr[i + 1]; ++p)
             d->v2c[H->cedge[p]] = v0;

@@ -467,8 +467,8 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         uint64_t *tr = nullptr;
         if (std::getenv("LDPC_AMD_PHASE_TRACE")) // debug build: per-wave phase timers of the first 2048 frames -> file
         {
-            check(hipMalloc(&tr, 2048 * 16 * 8), "trace");
-            check(hipMemset(tr, 0, 2048 * 16 * 8), "trace");
+            check(hipMalloc(&tr, 2048 * 32 * 8), "trace");
+            check(hipMemset(tr, 0, 2048 * 32 * 8), "trace");
             a.phase_trace = tr;
         }
 #endif
@@ -476,9 +476,9 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
 #ifdef LDPC_AMD_PHASE_TRACE
         if (tr)
         {
-            std::vector<uint64_t> h(2048 * 16);
+            std::vector<uint64_t> h(2048 * 32);
             check(hipDeviceSynchronize(), "sync");
-            check(hipMemcpy(h.data(), tr, 2048 * 16 * 8, hipMemcpyDeviceToHost), "trace");
+            check(hipMemcpy(h.data(), tr, 2048 * 32 * 8, hipMemcpyDeviceToHost), "trace");
             if (FILE *f = std::fopen(std::getenv("LDPC_AMD_PHASE_TRACE"), "wb"))
             {
                 std::fwrite(h.data(), 8, h.size(), f);

@@ -694,6 +694,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform: block descriptors load as scalars
+#ifdef LDPC_AMD_PHASE_TRACE
+    const uint64_t tr_entry = __builtin_amdgcn_s_memtime();
+#endif
     const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
 
     if (tid == 0)
@@ -701,7 +704,13 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 
     // ---- channel + LLR initialisation (device_channel.hpp) ----
     channel_init<kThreads>(a, frame, llr, tid);
+#ifdef LDPC_AMD_PHASE_TRACE
+    const uint64_t tr_chan0 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef LDPC_AMD_PHASE_TRACE
+    const uint64_t tr_chan = __builtin_amdgcn_s_memtime();
+#endif
 
     if (a.llr_in_dump)
     {
@@ -828,6 +837,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         // VN pass I.  A frame that converged after VN pass I-1 (or ran out of iterations) has made one CN pass
         // too many, which nothing reads: two barriers per iteration instead of three, no hard-bit array.
         PHASE_TIMERS
+#ifdef LDPC_AMD_PHASE_TRACE
+        const uint64_t tr_loop0 = __builtin_amdgcn_s_memtime();
+#endif
         for (;;)
         {
             PHASE_START
@@ -863,10 +875,11 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             for (int w = 0; w < kDecodeWaves; ++w)
                 any |= votes[ph][w];
 #ifdef LDPC_AMD_PHASE_TRACE
-            if (((I > 0 && !(any & 1)) || I == a.iterations) && a.phase_trace && frame < 2048 && lane == 0)
+            if (((I > 0 && !(any & 1)) || I == a.iterations) && a.phase_trace && frame >= 30000 && frame < 32048 && lane == 0)
             {
-                uint64_t *o = a.phase_trace + (frame * 4 + wave) * 4;
+                uint64_t *o = a.phase_trace + ((frame - 30000) * 4 + wave) * 8;
                 o[0] = tr_cn, o[1] = tr_w1, o[2] = tr_vn, o[3] = tr_w2;
+                o[4] = tr_loop0 - tr_entry, o[5] = __builtin_amdgcn_s_memtime() - tr_loop0, o[6] = ((tr_chan0 - tr_entry) << 32) | (tr_chan - tr_chan0);
             }
 #endif
             if (any & 2) // checked before the syndrome: an escaped frame's hard decisions mean nothing
@@ -1124,6 +1137,11 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         if (tid == 0)
             a.bit_errors[frame] = static_cast<uint32_t>(misc[0]);
     }
+#ifdef LDPC_AMD_PHASE_TRACE
+    if constexpr (RATIO)
+        if (a.phase_trace && frame >= 30000 && frame < 32048 && lane == 0)
+            a.phase_trace[((frame - 30000) * 4 + wave) * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO>

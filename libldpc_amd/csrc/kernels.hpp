@@ -78,7 +78,7 @@ struct DecodeArgs
     uint32_t *redo_count;
     const uint32_t *redo_list_in;
     const uint32_t *redo_count_in;
-    uint64_t *phase_trace; // debug builds with -DLDPC_AMD_PHASE_TRACE only: [2048 frames][4 waves][4 timers]
+    uint64_t *phase_trace; // debug builds with -DLDPC_AMD_PHASE_TRACE only: [2048 frames of mid-launch][4 waves][8 values]
 };
 
 // device copy of RegPlan (register-resident decoder, kernels_reg.hip)

@@ -142,3 +142,22 @@ def test_sharded_counters_equal_single_shard_gloo(tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_headline_kernel_register_budget():
+    """The likelihood-ratio decode kernel of the n=1024 code runs five frames per CU only while it fits 96 VGPRs
+    (512 / 5 waves per SIMD, allocated in eights) without scratch; the compiler's resource report of the last build
+    (libldpc_amd/build.py keeps it next to the object) must still say so.  Several attempted optimisations were
+    lost to exactly this boundary (profiles/README.md)."""
+    from libldpc_amd import build
+    res = build.kernel_resources("kernels.hip")
+    if res is None:
+        pytest.skip("no resource report (library built by something other than libldpc_amd.build)")
+    # decode_kernel<MINSUM=false, WANT_LLR=false, LDS_RESIDENT=true, MAXD=4, LLR_MODE=kLlrRegs, RATIO=true>
+    key = [k for k in res if "decode_kernelILb0ELb0ELb1ELi4ELi2ELb1E" in k]
+    assert len(key) == 1, key
+    r = res[key[0]]
+    assert r["VGPRs"] <= 96 and r["ScratchSize [bytes/lane]"] == 0 and r["Occupancy [waves/SIMD]"] >= 5, r
+    # the min-sum instantiation of the same code (BASELINE config 3)
+    key = [k for k in res if "decode_kernelILb1ELb0ELb1ELi4ELi2ELb0E" in k]
+    assert len(key) == 1 and res[key[0]]["VGPRs"] <= 96 and res[key[0]]["ScratchSize [bytes/lane]"] == 0, res[key[0]]

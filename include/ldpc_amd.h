@@ -134,8 +134,11 @@ uint64_t ldpc_hip_stream_frame(const ldpc_hip_ctx *ctx);
 uint64_t ldpc_hip_stream_raw_draws(const ldpc_hip_ctx *ctx);
 int ldpc_hip_synchronize(ldpc_hip_ctx *ctx, void *hip_stream);
 
-/* time kernels with HIP events recorded on the launch stream: which = 0 the decode kernel of the last
-   batch, 1 the noise-stream kernels (mt19937_64 generate + polar scan) of the last batch; milliseconds */
+/* time kernels with HIP events: which = 0 the decode launches (recorded on the launch stream), 1 the noise-stream
+   refills (mt19937_64 generate + polar scan, recorded on the library's internal stream).  Event pairs are queued
+   per launch; ldpc_hip_last_ms waits for them and returns the MEAN duration in milliseconds of the launches since
+   the previous call (so a caller that reads it once per launch sees that launch, and a caller that reads it after
+   a loop does not serialise the overlap of the noise stream with the decode) */
 void ldpc_hip_set_profiling(ldpc_hip_ctx *ctx, int on);
 float ldpc_hip_last_ms(ldpc_hip_ctx *ctx, int which);
 

@@ -1150,6 +1150,15 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
     decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO>(a);
 }
 
+// The same body compiled for five waves per SIMD (at most 96 VGPRs): the instantiations that sit at that boundary
+// anyway (narrow LDS-resident codes without the LLR output) are pinned there, so that a change that costs one or two
+// registers spills them instead of silently losing the fifth resident frame of every CU (-8 %).
+template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void decode_kernel_w5(const DecodeArgs a)
+{
+    decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO>(a);
+}
+
 // ---------------------------------------------------------------------------------------------
 // BEC: erasure decoder over the alphabet {0, 1, 'E'} (decoder.cpp:91-192), channel fused
 // (channel.cpp:199-229).  All state is bytes in LDS: msg[nnz], sym[nc] (decoder input), lout[nc].
@@ -1528,6 +1537,14 @@ int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *s
         k = want_llr ? decode_kernel<false, true, LDS_RESIDENT, MAXD, LLR_MODE, false>
                      : decode_kernel<false, false, LDS_RESIDENT, MAXD, LLR_MODE, false>;
     }
+    if constexpr (LDS_RESIDENT && MAXD == 4 && LLR_MODE == kLlrRegs)
+        if (!want_llr)
+        {
+            if (min_sum)
+                k = decode_kernel_w5<true, false, LDS_RESIDENT, MAXD, LLR_MODE, false>;
+            else if (ratio)
+                k = decode_kernel_w5<false, false, LDS_RESIDENT, MAXD, LLR_MODE, true>;
+        }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));
     if (e != hipSuccess)

@@ -202,8 +202,9 @@ def test_division_sequence_is_the_ieee_division(dec):
 
 def _oracle_chunk(args):
     """Worker (CPU only): frames [skip, skip+count) of the stream through the det-mode oracle."""
-    x, seed, skip, count = args
-    o = orc.Code(orc.H_TXT).run_frames("AWGN", x, seed=seed, skip=skip, count=count, math=orc.MATH_DET,
+    x, seed, skip, count = args[:4]
+    chan, ms = (args[4], args[5]) if len(args) > 4 else ("AWGN", False)
+    o = orc.Code(orc.H_TXT).run_frames(chan, x, seed=seed, skip=skip, count=count, math=orc.MATH_DET, min_sum=ms,
                                        want_vectors=False)
     return o["iters"], o["bit_errors"]
 
@@ -240,3 +241,21 @@ def test_bulk_100000_frames_vs_reference(dec, golden_bulk):
     assert np.array_equal(r["bit_errors"][conv], ref_be[conv])
     assert np.array_equal(r["bit_errors"] > 0, ref_be > 0)
     assert np.array_equal(r["iters"] >= 50, ~conv)
+
+
+@pytest.mark.parametrize("chan,x,ms,n", [("BSC", 0.24, False, 16384), ("AWGN", -4.5, True, 16384), ("BSC", 0.27, True, 8192)])
+def test_bulk_other_modes_bit_exact_vs_det_oracle(dec, chan, x, ms, n):
+    """The same bulk check for the BSC (sum-product in likelihood-ratio form on two-valued LLRs; ≈3 % of the frames
+    fail at 0.24) and for min-sum: iteration count and bit-error count of every frame equal the oracle's."""
+    import multiprocessing as mp
+    parts = 16
+    per = n // parts
+    with mp.get_context("fork").Pool(parts) as pool:
+        res = pool.map(_oracle_chunk, [(x, 4, k * per, per, chan, ms) for k in range(parts)])
+    it = np.concatenate([r[0] for r in res])
+    be = np.concatenate([r[1] for r in res])
+    dec.stream_begin(chan, 4, x)
+    r = dec.stream_decode(n, want=("iters", "bit_errors"), decoding="BP_MS" if ms else "BP")
+    assert np.array_equal(r["iters"], it)
+    assert np.array_equal(r["bit_errors"], be)
+    assert int((be > 0).sum()) > 10

@@ -370,3 +370,29 @@ def test_batch_counters_on_device(dec):
         torch.cuda.synchronize()
         assert torch.equal(c, ref), (c, ref)
         assert int(c[0]) == n and int(c[1]) > 0
+
+
+def _oracle_chunk_file(args):
+    path, chan, x, seed, skip, count, ms, early, iters = args
+    o = orc.Code(path).run_frames(chan, x, seed=seed, skip=skip, count=count, math=orc.MATH_DET, min_sum=ms,
+                                  early_term=early, iters=iters, want_vectors=False)
+    return o["iters"], o["bit_errors"]
+
+
+@pytest.mark.parametrize("x,ms,early,iters,n", [(1.4, False, True, 50, 4096), (1.2, True, True, 30, 2048),
+                                                (1.6, False, False, 10, 1024)])
+def test_8k_bulk_bit_exact_vs_det_oracle(dec8k, h8k_file, x, ms, early, iters, n):
+    """The register-resident kernel (config 4 code) over a few thousand frames near the decoding threshold, where
+    iteration counts spread from ~10 to the limit: every frame's iteration count and bit-error count equal the
+    oracle's (sum-product in ratio form with early termination, min-sum, and sum-product in the LLR domain)."""
+    import multiprocessing as mp
+    parts = 16
+    per = n // parts
+    with mp.get_context("fork").Pool(parts) as pool:
+        res = pool.map(_oracle_chunk_file, [(h8k_file, "AWGN", x, 6, k * per, per, ms, early, iters) for k in range(parts)])
+    it = np.concatenate([r[0] for r in res])
+    be = np.concatenate([r[1] for r in res])
+    dec8k.stream_begin("AWGN", 6, x)
+    r = dec8k.stream_decode(n, early_term=early, iterations=iters, decoding="BP_MS" if ms else "BP", want=("iters", "bit_errors"))
+    assert np.array_equal(r["iters"], it)
+    assert np.array_equal(r["bit_errors"], be)

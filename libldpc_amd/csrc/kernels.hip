@@ -1229,15 +1229,23 @@ __global__ __launch_bounds__(kThreads) void bec_kernel(const BecArgs a)
     for (int r = tid; r < nc; r += kThreads)
         lout[r] = 0; // mLLROut starts zeroed
 
-    const auto my_vn = uniform_table(P.vn_work + wave * P.vn_work_stride);
-    const auto my_cn = uniform_table(P.cn_work + wave * P.cn_work_stride);
+    // work lists with the block descriptors in place (plan.cpp): one scalar load per block, no dependent second one
+    const auto my_vdesc = uniform_table(P.vn_work_desc + wave * (P.vn_work_stride + 1) * 4);
+    const auto my_cdesc = uniform_table(reinterpret_cast<const uint32_t *>(P.cn_work_desc + wave * P.cn_desc_stride));
+    auto vn_desc = [&](int w) { // count 0 = none (every row ends in one)
+        const uint32_t d0 = my_vdesc[4 * w], d1 = my_vdesc[4 * w + 1], d2 = my_vdesc[4 * w + 2];
+        return VnBlock{d0, d1, static_cast<uint16_t>(d2 & 0xFFFFu), static_cast<uint16_t>(d2 >> 16)};
+    };
+    auto cn_desc = [&](int w) { // count 0 = none (every row ends in two)
+        const uint32_t d0 = my_cdesc[2 * w], d1 = my_cdesc[2 * w + 1];
+        return CnBlock{d0, static_cast<uint16_t>(d1 & 0xFFFFu), static_cast<uint16_t>(d1 >> 16)};
+    };
     // v2c init: decoder.cpp:96-99
     for (int w = 0; w < P.vn_work_stride; ++w)
     {
-        const uint32_t bi = my_vn[w];
-        if (bi == 0xFFFF)
+        const VnBlock b = vn_desc(w);
+        if (b.count == 0)
             break;
-        const VnBlock b = load_block3(P.vn_blocks, bi);
         if (lane < b.count)
         {
             uint8_t L = sym[b.first + lane];
@@ -1254,10 +1262,9 @@ __global__ __launch_bounds__(kThreads) void bec_kernel(const BecArgs a)
         // ---- CN update: decoder.cpp:105-123 ----
         for (int w = 0; w < P.cn_work_stride; ++w)
         {
-            const uint32_t bi = my_cn[w];
-            if (bi == 0xFFFF)
+            const CnBlock b = cn_desc(w);
+            if (b.count == 0)
                 break;
-            const CnBlock b = load_block2(P.cn_blocks, bi);
             if (lane < b.count)
             {
                 uint8_t *m = msg + b.off + lane;
@@ -1287,10 +1294,9 @@ __global__ __launch_bounds__(kThreads) void bec_kernel(const BecArgs a)
         int any_e = 0;
         for (int w = 0; w < P.vn_work_stride; ++w)
         {
-            const uint32_t bi = my_vn[w];
-            if (bi == 0xFFFF)
+            const VnBlock b = vn_desc(w);
+            if (b.count == 0)
                 break;
-            const VnBlock b = load_block3(P.vn_blocks, bi);
             if (lane < b.count)
             {
                 const int r = b.first + lane;

@@ -222,6 +222,17 @@ const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream)
     const uint32_t n = static_cast<uint32_t>(c_hi - c_lo);
     uint64_t *st = static_cast<uint64_t *>(states_.get());
     uint64_t *raw = static_cast<uint64_t *>(raw_.reserve(sizeof(uint64_t) * kChunkWords * n));
+    if (n == 1)
+    {
+        // a short request inside one chunk (single frames, small batches): only the prefix of the chunk that is asked
+        // for is generated (whole twist rounds of 312 words); the state after the chunk is then not produced
+        const uint64_t need = (first + count - c_lo * kChunkWords + kMtWords - 1) / kMtWords * kMtWords;
+        if (need < kChunkWords)
+        {
+            check(launch_mt_generate(st + (c_lo - base_) * kMtWords, nullptr, raw, 1, static_cast<uint32_t>(need), s), "mt_generate");
+            return raw + (first - c_lo * kChunkWords);
+        }
+    }
     uint64_t *next_last = st + (c_hi - base_) * kMtWords;
     check(launch_mt_generate(st + (c_lo - base_) * kMtWords, next_last, raw, n, static_cast<uint32_t>(kChunkWords), s),
           "mt_generate");

@@ -151,6 +151,12 @@ int ldpc_hip_mt64(ldpc_hip_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, 
    the IEEE division; *mismatches receives the number of pairs whose quotients differ in any bit (expected: 0) */
 int ldpc_hip_selftest_division(ldpc_hip_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *mismatches);
 
+/* host-only self-test of the noise stream's chunk-state table bookkeeping (no GPU needed): replays n_requests sequential
+   generate requests of chunks_per_request chunks each, starting at chunk first_chunk, and returns the largest table row
+   any step reads or writes (must be <= 8192, the last row of the table), or UINT64_MAX if a request was left without a
+   valid row */
+uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per_request, uint64_t n_requests);
+
 /* the simulation loop of ldpc_sim::start (ldpcsim.cpp:97-263) on one context; totals[4*i..] =
    {frames, fec, bec, iters} per channel point.  Returns the number of channel points, <0 on error. */
 int ldpc_hip_simulate(ldpc_hip_ctx *ctx, decoder_param dec, channel_param ch, simulation_param sim,

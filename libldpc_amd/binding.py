@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libldpc.so")
+# LDPC_AMD_LIB selects another build of the library (same-box A/B runs, tools/ab.sh); the default is the in-tree product
+LIB_PATH = os.environ.get("LDPC_AMD_LIB") or os.path.join(PKG, "libldpc.so")
 
 AWGN, BSC, BEC = 1, 2, 3
 CHANNELS = {"AWGN": AWGN, "BSC": BSC, "BEC": BEC}
@@ -78,6 +79,8 @@ def load_library(path=LIB_PATH):
     L.ldpc_hip_set_profiling.argtypes = [vp, i32]
     L.ldpc_hip_last_ms.restype = ct.c_float
     L.ldpc_hip_last_ms.argtypes = [vp, i32]
+    L.ldpc_hip_selftest_chunk_table.restype = u64
+    L.ldpc_hip_selftest_chunk_table.argtypes = [u64, u64, u64]
     L.ldpc_hip_simulate.restype = i32
     L.ldpc_hip_simulate.argtypes = [vp, decoder_param, channel_param, simulation_param, ct.POINTER(sim_results_t),
                                     vp, ct.POINTER(ct.c_bool), i32]

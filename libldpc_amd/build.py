@@ -26,6 +26,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 if os.environ.get("LDPC_AMD_PHASE_TRACE_BUILD"):  # debug build with per-wave phase timers (tools/phase_probe.py)
     FLAGS.append("-DLDPC_AMD_PHASE_TRACE")
+# objects are cached per flag set, so a debug build never mixes with normal objects
+import hashlib
+OBJ = os.path.join(OBJ, hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()[:10])
+if os.environ.get("LDPC_AMD_PHASE_TRACE_BUILD"):
+    LIB = os.path.join(PKG, "libldpc_trace.so")  # load it with LDPC_AMD_LIB; the product library stays as built
+    CLI = os.path.join(OBJ, "ldpcsim_trace")
 
 
 def _stale(target, deps):
@@ -105,7 +111,7 @@ def build(verbose=False):
     cli_objs = [objs[s] for s in CLI_SOURCES if s in objs]
     if cli_objs and _stale(CLI, cli_objs + [LIB]):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-o", CLI] + cli_objs +
-                              ["-L" + PKG, "-l:libldpc.so", "-Wl,-rpath,$ORIGIN"])
+                              ["-L" + PKG, "-l:" + os.path.basename(LIB), "-Wl,-rpath,$ORIGIN"])
     if verbose:
         print("built", LIB, "and", CLI if cli_objs else "(no CLI)")
     return LIB

@@ -345,6 +345,42 @@ int ldpc_hip_selftest_division(ldpc_hip_ctx *ctx, uint64_t n, uint64_t seed, uin
     });
 }
 
+uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per_request, uint64_t n_requests)
+{
+    // host-only replay of MtStream's table bookkeeping: sequential requests, as a long Monte-Carlo run issues them
+    ChunkTable t;
+    uint64_t max_row = 0, c = first_chunk;
+    std::vector<ChunkTableOp> ops;
+    try
+    {
+        for (uint64_t i = 0; i < n_requests; ++i, c += chunks_per_request)
+        {
+            ops.clear();
+            t.ensure(c, c + chunks_per_request, ops);
+            for (const ChunkTableOp &op : ops)
+                if (op.kind == ChunkTableOp::kRebase)
+                    max_row = std::max<uint64_t>(max_row, op.a);
+                else if (op.kind == ChunkTableOp::kJump)
+                    max_row = std::max<uint64_t>(max_row, 2ull * op.a - 1);
+            if (c < t.base() || c + chunks_per_request - t.base() > t.ready())
+                return ~0ull; // a requested chunk has no valid row
+            max_row = std::max<uint64_t>(max_row, c + chunks_per_request - 1 - t.base());
+            const int64_t nr = t.next_row(c + chunks_per_request);
+            if (nr >= 0)
+            {
+                max_row = std::max<uint64_t>(max_row, static_cast<uint64_t>(nr));
+                t.note_next_written(c + chunks_per_request);
+            }
+        }
+    }
+    catch (const std::exception &e)
+    {
+        g_err = e.what();
+        return ~0ull;
+    }
+    return max_row;
+}
+
 int ldpc_hip_simulate(ldpc_hip_ctx *ctx, decoder_param dec, channel_param ch, simulation_param sim,
                       sim_results_t *results, uint64_t *totals, bool *stopFlag, int cli_output)
 {

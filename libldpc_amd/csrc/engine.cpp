@@ -126,35 +126,20 @@ void *DeviceBuffer::reserve(size_t bytes)
 }
 
 // ---------------------------------------------------------------------------------------------
-void MtStream::reset(uint64_t seed)
+void ChunkTable::ensure(uint64_t c_lo, uint64_t c_hi, std::vector<ChunkTableOp> &ops)
 {
-    if (valid_ && seed == seed_)
-        return; // chunk states depend on the seed only; keep them
-    seed_ = seed;
-    valid_ = false;
-}
-
-void MtStream::ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream)
-{
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t row = sizeof(uint64_t) * kMtWords;
-    uint64_t *st = static_cast<uint64_t *>(states_.reserve(row * (kStateCap + 1)));
-    if (c_hi - c_lo > kStateCap)
+    if (c_hi - c_lo > kCap)
         throw std::runtime_error("mt19937_64 stream request exceeds the chunk-state table");
     if (!valid_ || c_lo < base_)
     {
-        uint64_t w0[kMtWords];
-        mt64_window0(seed_, w0);
-        check(hipMemcpyAsync(st, w0, row, hipMemcpyHostToDevice, s), "upload window0");
-        check(hipStreamSynchronize(s), "sync"); // w0 is a stack buffer
+        ops.push_back({ChunkTableOp::kUploadWindow0, 0, 0});
         base_ = 0;
         ready_ = 1;
         pow_ready_ = 1;
         valid_ = true;
     }
     auto rebase = [&](uint64_t c) {
-        const uint64_t r = c - base_;
-        check(hipMemcpyAsync(st, st + r * kMtWords, row, hipMemcpyDeviceToDevice, s), "rebase");
+        ops.push_back({ChunkTableOp::kRebase, static_cast<uint32_t>(c - base_), 0});
         base_ = c;
         ready_ = 1;
         pow_ready_ = 1;
@@ -164,14 +149,14 @@ void MtStream::ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream)
         const uint64_t need = c_hi - base_;
         if (need <= ready_)
             return;
-        if (need > kStateCap)
+        if (need > kCap)
         {
             if (c_lo - base_ < ready_)
             {
                 rebase(c_lo);
                 continue;
             }
-            if (pow_ready_ >= kStateCap) // far seek: stride forward by the table length
+            if (pow_ready_ >= kCap) // far seek: stride forward by the table length
             {
                 rebase(base_ + ready_ - 1);
                 continue;
@@ -181,11 +166,52 @@ void MtStream::ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream)
         unsigned m = 0;
         while ((1u << m) < pow_ready_)
             ++m;
-        check(launch_mt_jump(st, st + static_cast<size_t>(pow_ready_) * kMtWords, device_poly(m, stream), pow_ready_, s),
-              "mt_jump");
+        ops.push_back({ChunkTableOp::kJump, pow_ready_, m});
         pow_ready_ *= 2;
         ready_ = std::max(ready_, pow_ready_);
     }
+}
+
+void ChunkTable::note_next_written(uint64_t c_hi)
+{
+    if (c_hi - base_ == ready_ && ready_ <= kCap)
+        ++ready_; // the state that follows the last generated chunk came for free (row index ready_ <= kCap)
+}
+
+void MtStream::reset(uint64_t seed)
+{
+    if (seeded_ && seed == seed_)
+        return; // chunk states depend on the seed only; keep them
+    seed_ = seed;
+    seeded_ = true;
+    table_.invalidate();
+}
+
+void MtStream::ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t row = sizeof(uint64_t) * kMtWords;
+    uint64_t *st = static_cast<uint64_t *>(states_.reserve(row * (kStateCap + 1)));
+    std::vector<ChunkTableOp> ops;
+    table_.ensure(c_lo, c_hi, ops);
+    for (const ChunkTableOp &op : ops)
+        switch (op.kind)
+        {
+        case ChunkTableOp::kUploadWindow0:
+        {
+            uint64_t w0[kMtWords];
+            mt64_window0(seed_, w0);
+            check(hipMemcpyAsync(st, w0, row, hipMemcpyHostToDevice, s), "upload window0");
+            check(hipStreamSynchronize(s), "sync"); // w0 is a stack buffer
+            break;
+        }
+        case ChunkTableOp::kRebase:
+            check(hipMemcpyAsync(st, st + static_cast<size_t>(op.a) * kMtWords, row, hipMemcpyDeviceToDevice, s), "rebase");
+            break;
+        case ChunkTableOp::kJump:
+            check(launch_mt_jump(st, st + static_cast<size_t>(op.a) * kMtWords, device_poly(op.b, stream), op.a, s), "mt_jump");
+            break;
+        }
 }
 
 // device copy of t^(J*2^m) mod phi, uploaded once per stream object
@@ -222,6 +248,7 @@ const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream)
     const uint32_t n = static_cast<uint32_t>(c_hi - c_lo);
     uint64_t *st = static_cast<uint64_t *>(states_.get());
     uint64_t *raw = static_cast<uint64_t *>(raw_.reserve(sizeof(uint64_t) * kChunkWords * n));
+    const uint64_t base = table_.base();
     if (n == 1)
     {
         // a short request inside one chunk (single frames, small batches): only the prefix of the chunk that is asked
@@ -229,15 +256,17 @@ const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream)
         const uint64_t need = (first + count - c_lo * kChunkWords + kMtWords - 1) / kMtWords * kMtWords;
         if (need < kChunkWords)
         {
-            check(launch_mt_generate(st + (c_lo - base_) * kMtWords, nullptr, raw, 1, static_cast<uint32_t>(need), s), "mt_generate");
+            check(launch_mt_generate(st + (c_lo - base) * kMtWords, nullptr, raw, 1, static_cast<uint32_t>(need), s), "mt_generate");
             return raw + (first - c_lo * kChunkWords);
         }
     }
-    uint64_t *next_last = st + (c_hi - base_) * kMtWords;
-    check(launch_mt_generate(st + (c_lo - base_) * kMtWords, next_last, raw, n, static_cast<uint32_t>(kChunkWords), s),
+    // the state that follows the last chunk comes for free, when the table has a row for it (rows 0..kStateCap)
+    const int64_t nr = table_.next_row(c_hi);
+    uint64_t *next_last = nr >= 0 ? st + static_cast<size_t>(nr) * kMtWords : nullptr;
+    check(launch_mt_generate(st + (c_lo - base) * kMtWords, next_last, raw, n, static_cast<uint32_t>(kChunkWords), s),
           "mt_generate");
-    if (c_hi - base_ == ready_ && ready_ <= kStateCap)
-        ++ready_; // the state that follows the last generated chunk comes for free
+    if (next_last)
+        table_.note_next_written(c_hi);
     return raw + (first - c_lo * kChunkWords);
 }
 
@@ -289,6 +318,25 @@ Engine::~Engine()
 
 void Engine::set_profiling(bool on) { profiling_ = on; }
 
+// Every public entry point binds the calling thread to this engine's GPU: the current device is per-thread state, and
+// a context used from a new thread (or after another engine switched devices) would otherwise launch on device 0 with
+// this device's pointers.
+void Engine::bind_device()
+{
+    if (!device_checked_)
+    {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= device_)
+        {
+            (void)hipGetLastError();
+            throw std::runtime_error("no usable HIP device (MI355X required): " + std::string(hipGetErrorString(e)));
+        }
+        device_checked_ = true;
+    }
+    check(hipSetDevice(device_), "hipSetDevice");
+}
+
 // Event pairs are queued per launch and only read back in last_ms(), so that profiling does not serialise
 // the noise stream of batch s+1 behind the decode of batch s.
 void Engine::prof_mark(int which, void *stream)
@@ -320,6 +368,7 @@ void Engine::prof_mark(int which, void *stream)
 // mean duration (ms) of the launches of kind `which` (0 decode kernel, 1 noise stream) since the previous call
 float Engine::last_ms(int which)
 {
+    bind_device();
     auto &q = prof_pending_[which ? 1 : 0];
     double sum = 0;
     size_t spans = 0;
@@ -340,13 +389,9 @@ float Engine::last_ms(int which)
 
 void Engine::upload_plan()
 {
+    bind_device();
     if (dev_.cn_blocks)
         return;
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= device_)
-        throw std::runtime_error("no usable HIP device (MI355X required): " + std::string(hipGetErrorString(e)));
-    check(hipSetDevice(device_), "hipSetDevice");
     auto up = [&](const void *src, size_t bytes) -> void * {
         void *d = nullptr;
         check(hipMalloc(&d, std::max<size_t>(bytes, 16)), "hipMalloc plan");
@@ -397,7 +442,11 @@ void Engine::upload_plan()
     dev_.lds_bytes = static_cast<uint32_t>(p.lds_bytes);
 }
 
-void Engine::synchronize(void *stream) { check(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "sync"); }
+void Engine::synchronize(void *stream)
+{
+    bind_device();
+    check(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "sync");
+}
 
 // frames per launch: bounded so that the noise-stream buffers and the memory-resident workspace stay modest
 uint64_t Engine::max_sub_batch() const
@@ -639,6 +688,7 @@ void Engine::stream_rewind_encoder(uint64_t frames_back, void *stream)
         return;
     if (frames_back > last_enc_n_)
         throw std::runtime_error("stream_rewind_encoder: more frames than the last batch held");
+    bind_device();
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t nc = plan_.nc;
     const uint8_t *src = frames_back == last_enc_n_

@@ -60,12 +60,48 @@ class DeviceBuffer
     size_t size_ = 0;
 };
 
+// Bookkeeping of the chunk-start-state table of one stream (host only, no HIP calls: unit-testable without a GPU,
+// ldpc_hip_selftest_chunk_table).  Row r of the device table holds the generator state at the start of chunk
+// base()+r; rows [0, ready()) are valid; the table has kCap+1 rows (0..kCap).
+struct ChunkTableOp
+{
+    enum Kind
+    {
+        kUploadWindow0, // row 0 := state of chunk 0 (from the seed)
+        kRebase,        // row 0 := row a
+        kJump           // rows [a, 2a) := rows [0, a) advanced by a chunks (polynomial index b: a == 1 << b)
+    } kind;
+    uint32_t a, b;
+};
+
+class ChunkTable
+{
+  public:
+    static constexpr uint32_t kCap = 8192;
+    void invalidate() { valid_ = false; }
+    uint64_t base() const { return base_; }
+    uint32_t ready() const { return ready_; }
+    // append the operations that make the states of chunks [c_lo, c_hi) available as rows [c_lo-base, c_hi-base)
+    void ensure(uint64_t c_lo, uint64_t c_hi, std::vector<ChunkTableOp> &ops);
+    // row that may receive the state FOLLOWING chunk c_hi-1 when a generate launch over [c_lo, c_hi) produces it for
+    // free, or -1 when the table has no row for it
+    int64_t next_row(uint64_t c_hi) const { return c_hi - base_ <= kCap ? static_cast<int64_t>(c_hi - base_) : -1; }
+    // the launch wrote next_row(c_hi)
+    void note_next_written(uint64_t c_hi);
+
+  private:
+    bool valid_ = false;
+    uint64_t base_ = 0;      // chunk id of row 0
+    uint32_t ready_ = 0;     // rows [0, ready_) hold chunk start states
+    uint32_t pow_ready_ = 0; // power-of-two prefix obtained by doubling
+};
+
 // One mt19937_64(seed) stream: chunk start states by jump-ahead, raw words generated on demand.
 class MtStream
 {
   public:
     static constexpr uint64_t kChunkWords = 3360 * kMtWords; // 1048320 words = 8 MB per chunk
-    static constexpr uint32_t kStateCap = 8192;
+    static constexpr uint32_t kStateCap = ChunkTable::kCap;
     void reset(uint64_t seed);
     uint64_t seed() const { return seed_; }
     // Generate raw outputs [first, first+count) of the stream; returns a device pointer to word `first`.
@@ -75,10 +111,8 @@ class MtStream
     void ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream);
     const uint64_t *device_poly(unsigned m, void *stream);
     uint64_t seed_ = 0;
-    bool valid_ = false;
-    uint64_t base_ = 0;   // chunk id of state row 0
-    uint32_t ready_ = 0;  // rows [0, ready_) hold chunk start states
-    uint32_t pow_ready_ = 0; // power-of-two prefix obtained by doubling
+    bool seeded_ = false;
+    ChunkTable table_;
     unsigned polys_uploaded_ = 0;
     DeviceBuffer states_, raw_, poly_;
 };
@@ -121,6 +155,7 @@ class Engine
     float last_ms(int which);
 
   private:
+    void bind_device();
     void upload_plan();
     void run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, uint64_t n, void *stream);
     void run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const uint8_t *codeword, void *stream);
@@ -135,6 +170,7 @@ class Engine
     DevPlan dev_{};
     DevRegPlan dev_reg_{};
     int device_ = 0;
+    bool device_checked_ = false;
     std::vector<void *> owned_;
 
     // stream state

@@ -35,6 +35,18 @@ def test_header_symbols_are_exported(lib):
     assert exported == declared, exported ^ declared  # nothing else leaks out of the library
 
 
+def test_chunk_state_table_never_leaves_its_rows(lib):
+    """Host replay of the noise stream's chunk-state bookkeeping over far more sequential requests than the table has
+    rows (8193: indices 0..8192): a long Monte-Carlo run of one-chunk batches (BSC/BEC batches, the encoder's info
+    stream) must never read or write row 8193, and every requested chunk must have a valid row."""
+    cap = 8192
+    for first, per, n in [(0, 1, 3 * cap + 7), (0, 2, 2 * cap), (0, 3, cap), (5, 64, 2000), (0, cap, 5), (123456, 1, cap + 50),
+                          (0, 7, 4000), (cap - 1, 1, 10), (cap, 1, 10), (0, cap - 1, 3)]:
+        top = lib.ldpc_hip_selftest_chunk_table(first, per, n)
+        assert top <= cap, (first, per, n, top)
+    assert lib.ldpc_hip_selftest_chunk_table(0, cap + 1, 1) == 2**64 - 1  # larger than the table: refused, not overrun
+
+
 def test_struct_layouts_match_reference_abi():
     """x86-64 SysV sizes/offsets of the by-value structs (functions.h:107-127)."""
     from libldpc_amd.binding import channel_param, decoder_param, sim_results_t, simulation_param

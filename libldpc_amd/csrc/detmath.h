@@ -389,4 +389,53 @@ DM_FN double dm_ratio_lambda(double x, double y) { return dm_ratio_div(x + y, DM
 /* the same two with one operand given as a fraction n/d (a partial result not yet divided) */
 DM_FN double dm_ratio_lambda_frac(double n, double d, double y) { return dm_ratio_div(DM_FMA(d, y, n), DM_FMA(n, y, d)); }
 
+/*
+ * Check nodes of any degree without dividing partial results: a partial result of the forward/backward recursion
+ * (decoder.cpp:31-44) over m >= 2 inputs is carried as the fraction rho = n / d,
+ *     first two inputs   a [+] b : n = 1 + a b,   d = a + b
+ *     one more input     f [+] c : n' = f.d + f.n c,  d' = f.n + f.d c
+ * and divided only where a c2v message leaves the node:
+ *     lambda(f [+] c) = (f.n + f.d c) / (f.d + f.n c)                              (dm_ratio_lambda_frac)
+ *     lambda(f [+] g) = (f.n g.d + f.d g.n) / (f.d g.d + f.n g.n)                  (dm_frac_lambda2)
+ * so a degree-D node costs D divisions instead of 3(D-2).  Every operand is positive: no cancellation.
+ * Magnitudes: inputs lie in [2^-240, 2^240).  A partial over an ODD number m >= 3 of inputs is rescaled, right
+ * after it has been formed, by the power of two that brings n into [1, 2) (dm_frac_norm: exact, it changes no
+ * later rounding); then n < 2^721, d < 2^722 before a rescale and n < 2^481, d < 2^482 for every stored partial,
+ * and the products of dm_frac_lambda2 stay below 2^964.  From below, n and d never fall under 2^-241.
+ */
+typedef struct
+{
+    double n, d;
+} dm_frac;
+
+DM_FN dm_frac dm_frac_first(double a, double b)
+{
+    dm_frac f;
+    f.n = DM_FMA(a, b, 1.0);
+    f.d = a + b;
+    return f;
+}
+DM_FN dm_frac dm_frac_step(dm_frac f, double c)
+{
+    dm_frac g;
+    g.n = DM_FMA(f.n, c, f.d);
+    g.d = DM_FMA(f.d, c, f.n);
+    return g;
+}
+DM_FN dm_frac dm_frac_norm(dm_frac f)
+{
+    /* s = 2^-(unbiased exponent of n): exponent field of s = 2046 - exponent field of n */
+    double s = dm_from_bits(0x7FE0000000000000ull - (dm_bits(f.n) & 0x7FF0000000000000ull));
+    dm_frac g;
+    g.n = f.n * s;
+    g.d = f.d * s;
+    return g;
+}
+DM_FN double dm_frac_lambda2(dm_frac f, dm_frac g)
+{
+    double num = DM_FMA(f.n, g.d, f.d * g.n);
+    double den = DM_FMA(f.n, g.n, f.d * g.d);
+    return dm_ratio_div(num, den);
+}
+
 #endif /* LDPC_AMD_DETMATH_H */

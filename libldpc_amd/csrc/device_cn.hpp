@@ -73,7 +73,7 @@ __device__ __forceinline__ void cn_core(double (&v)[D])
 
 // Likelihood-ratio form of the same recursion (detmath.h, "Likelihood-ratio form"): v[j] = rho(v2c_j) on entry,
 // lambda(c2v_j) on return.  Partial results F[j], B[j] are carried as rho; the last box-plus of every output is
-// taken directly in lambda form, so a degree-3 node costs three divisions and a degree-4 node four (its two
+// taken directly in lambda form, so a degree-3 node costs three divisions and a node of degree D >= 4 costs D (its
 // partial results stay undivided fractions).
 template <int D>
 __device__ __forceinline__ void cn_ratio(double (&v)[D])
@@ -102,21 +102,36 @@ __device__ __forceinline__ void cn_ratio(double (&v)[D])
     }
     else
     {
-        double F[D], B[D];
-        F[0] = v[0];
-        B[D - 1] = v[D - 1];
+        // D >= 5: partial results stay undivided fractions (detmath.h, dm_frac): D divisions, not 3(D-2).
+        // F[j] = inputs 0..j, B[j] = inputs j..D-1; a partial over an odd number >= 3 of inputs is rescaled.
+        dm_frac F[D], B[D];
+        F[1] = dm_frac_first(v[0], v[1]);
+        B[D - 2] = dm_frac_first(v[D - 1], v[D - 2]);
 #pragma unroll
-        for (int j = 1; j <= D - 3; ++j)
-            F[j] = dm_ratio_rho(F[j - 1], v[j]);
+        for (int j = 2; j <= D - 3; ++j)
+        {
+            F[j] = dm_frac_step(F[j - 1], v[j]);
+            if ((j + 1) % 2 == 1)
+                F[j] = dm_frac_norm(F[j]);
+        }
 #pragma unroll
-        for (int j = D - 2; j >= 2; --j)
-            B[j] = dm_ratio_rho(B[j + 1], v[j]);
-        const double o0 = dm_ratio_lambda(B[2], v[1]);
-        const double oL = dm_ratio_lambda(F[D - 3], v[D - 2]);
+        for (int j = D - 3; j >= 2; --j)
+        {
+            B[j] = dm_frac_step(B[j + 1], v[j]);
+            if ((D - j) % 2 == 1)
+                B[j] = dm_frac_norm(B[j]);
+        }
+        double o[D];
+        o[0] = dm_ratio_lambda_frac(B[2].n, B[2].d, v[1]);             // B[1] = B[2] [+] v[1]
+        o[1] = dm_ratio_lambda_frac(B[2].n, B[2].d, v[0]);             // F[0] [+] B[2]
+        o[D - 2] = dm_ratio_lambda_frac(F[D - 3].n, F[D - 3].d, v[D - 1]); // F[D-3] [+] B[D-1]
+        o[D - 1] = dm_ratio_lambda_frac(F[D - 3].n, F[D - 3].d, v[D - 2]); // F[D-2] = F[D-3] [+] v[D-2]
 #pragma unroll
-        for (int j = 1; j < D - 1; ++j)
-            v[j] = dm_ratio_lambda(F[j - 1], B[j + 1]);
-        v[0] = o0, v[D - 1] = oL;
+        for (int j = 2; j <= D - 3; ++j)
+            o[j] = dm_frac_lambda2(F[j - 1], B[j + 1]);
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            v[j] = o[j];
     }
 }
 

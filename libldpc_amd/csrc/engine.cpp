@@ -292,6 +292,13 @@ Engine::Engine(const std::string &pc_file, const std::string &gen_file, int devi
             if (reg_plan_.ok)
                 break;
         }
+        // second form (totals come back instead of messages): preferred when the code fits its one instantiation
+        if (reg_plan_.ok && !std::getenv("LDPC_AMD_NO_REG2"))
+        {
+            // 512 threads x 256 registers (two waves per SIMD, eight check nodes per thread) or 1024 x 128
+            const bool nt1024 = std::getenv("LDPC_AMD_REG2_NT1024") != nullptr;
+            reg2_plan_ = nt1024 ? build_reg2_plan(*code_, plan_, 1024, 4, 6, 4, 4) : build_reg2_plan(*code_, plan_, 512, 8, 6, 8, 8);
+        }
     }
 }
 
@@ -433,6 +440,18 @@ void Engine::upload_plan()
         dev_reg_.vn_blocks = static_cast<const RegVnBlock *>(up(r.vn_blocks.data(), r.vn_blocks.size() * sizeof(RegVnBlock)));
         dev_reg_.round_first = static_cast<const uint32_t *>(up(r.round_first.data(), r.round_first.size() * 4));
     }
+    if (reg2_plan_.ok)
+    {
+        const Reg2Plan &r = reg2_plan_;
+        dev_reg2_.nt = r.nt, dev_reg2_.kc = r.kc, dev_reg2_.maxd = r.maxd, dev_reg2_.nv0 = r.nv0, dev_reg2_.nv1 = r.nv1;
+        dev_reg2_.neutral = r.neutral, dev_reg2_.lds_entries = r.lds_entries;
+        dev_reg2_.edge_w = static_cast<const uint32_t *>(up(r.edge_w.data(), r.edge_w.size() * 4));
+        dev_reg2_.round0_mask = static_cast<const uint64_t *>(up(r.round0_mask.data(), r.round0_mask.size() * 8));
+        dev_reg2_.round1_mask = static_cast<const uint64_t *>(up(r.round1_mask.data(), r.round1_mask.size() * 8));
+        dev_reg2_.cn_deg = static_cast<const uint8_t *>(up(r.cn_deg.data(), r.cn_deg.size()));
+        dev_reg2_.vn_blocks = static_cast<const Reg2VnBlock *>(up(r.vn_blocks.data(), r.vn_blocks.size() * sizeof(Reg2VnBlock)));
+        dev_reg2_.vn_rank = static_cast<const uint32_t *>(up(r.vn_rank.data(), r.vn_rank.size() * 4));
+    }
     if (code_->has_G())
     {
         std::vector<uint32_t> cp(code_->G.cptr.begin(), code_->G.cptr.end()), cr(code_->G.crow.begin(), code_->G.crow.end());
@@ -495,7 +514,10 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         {
             a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
             a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nc));
-            check(launch_decode_reg(a, dev_reg_, p.min_sum, s), "decode (register-resident)");
+            if (reg2_plan_.ok)
+                check(launch_decode_reg2(a, dev_reg2_, p.min_sum, s), "decode (register-resident, totals form)");
+            else
+                check(launch_decode_reg(a, dev_reg_, p.min_sum, s), "decode (register-resident)");
         }
         else if (plan_.hbm_ok)
         {

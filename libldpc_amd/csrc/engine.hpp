@@ -126,6 +126,7 @@ class Engine
     const LdpcCode &code() const { return *code_; }
     const Plan &plan() const { return plan_; }
     const RegPlan &reg_plan() const { return reg_plan_; }
+    const Reg2Plan &reg2_plan() const { return reg2_plan_; }
     int device() const { return device_; }
     bool bec_deg1_compat = false;
 
@@ -167,8 +168,10 @@ class Engine
     std::unique_ptr<LdpcCode> code_;
     Plan plan_;
     RegPlan reg_plan_;
+    Reg2Plan reg2_plan_;
     DevPlan dev_{};
     DevRegPlan dev_reg_{};
+    DevReg2Plan dev_reg2_{};
     int device_ = 0;
     bool device_checked_ = false;
     std::vector<void *> owned_;

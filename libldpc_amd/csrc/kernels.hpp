@@ -93,6 +93,19 @@ struct DevRegPlan
     const uint32_t *round_first;
 };
 
+// device copy of Reg2Plan (register-resident decoder, second form: kernels_reg2.hip)
+struct DevReg2Plan
+{
+    int nt, kc, maxd, nv0, nv1;
+    uint32_t neutral, lds_entries;
+    const uint32_t *edge_w;
+    const uint64_t *round0_mask;
+    const uint64_t *round1_mask;
+    const uint8_t *cn_deg;
+    const Reg2VnBlock *vn_blocks;
+    const uint32_t *vn_rank;
+};
+
 // BEC (u8 erasure alphabet, decoder.cpp:91-192 + channel.cpp:199-229)
 struct BecArgs
 {
@@ -121,6 +134,8 @@ int launch_decode_lds(const DecodeArgs &a, bool min_sum, int max_cn_degree, int 
 int launch_decode_mem(const DecodeArgs &a, bool min_sum, int max_cn_degree, uint32_t occupancy_lds, void *stream);
 // register-resident decoder: a.ws_llr [n][nc] doubles and a.ws_hb [n][nc] bytes must be set
 int launch_decode_reg(const DecodeArgs &a, const DevRegPlan &r, bool min_sum, void *stream);
+// register-resident decoder, second form (same workspace requirements)
+int launch_decode_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, void *stream);
 int launch_bec(const BecArgs &a, void *stream);
 
 // ---- mt19937_64 on the device ----

@@ -1,0 +1,399 @@
+// kernels_reg2.hip — register-resident BP / min-sum decoder, second form (BASELINE config 4: (3,6)-regular
+// n=8192, 196 KB of fp64 messages per frame: more than one CU's LDS).
+//
+// One workgroup of NT threads (1024 or 512) decodes one frame on one CU.  Thread (wave, lane) owns the check nodes of CN blocks
+// k*16 + wave (k < KC) and holds their KC x MAXD messages in registers for the whole decode, together with — packed in
+// one word per edge — where the edge's c2v message goes in the LDS mailbox and where the total of the edge's variable
+// node comes back from.  What differs from kernels_reg.hip (which stays as the general fallback):
+//
+//   * the edge's owner forms the v2c message itself.  decoder.cpp:50-64 computes  out = LLRin + sum of c2v  and then
+//     v2c_e = out - c2v_e  per edge; the subtraction (ratio form: the product  rho(total) * lambda(c2v_e) ) needs only the
+//     node's total and the edge's own c2v, which its owner still has in a register.  So the variable-node thread sends
+//     back ONE 8-byte total per node instead of a message and a hard-decision byte per edge, and the decision rides in
+//     the total (its sign in the ratio form, out <= 0 in the LLR domain): no hard-bit array, the syndrome
+//     (decoder.h:47-64) is an XOR over the totals a check node gathers anyway;
+//   * input LLRs live in the registers of the variable-node threads (NV0 + NV1 nodes per thread), no device memory
+//     in the iteration loop;
+//   * two mailbox rounds per iteration, five barriers: gather + vote | CN pass + scatter round 0 | VN round 0 |
+//     scatter round 1 | VN round 1;
+//   * check nodes of degree >= 5 keep their partial results as undivided fractions (detmath.h, dm_frac).
+//
+// Same arithmetic, same order as the LDS-resident kernel (kernels.hip) and as the reference:
+//   decode loop src/decoding/decoder.cpp:11-78, CN recursion :31-44 (device_cn.hpp), VN sum :50-56 in column
+//   file order, syndrome src/decoding/decoder.h:47-64, channels src/sim/channel.cpp (device_channel.hpp).
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+#include "device_channel.hpp"
+#include "device_cn.hpp"
+#include "device_math.hpp"
+#include "kernels.hpp"
+
+namespace ldpc_amd
+{
+
+namespace
+{
+
+template <bool MINSUM, bool RATIO, int MAXD>
+__device__ __forceinline__ void cn_regs2(double (&m)[MAXD], int degree)
+{
+    // wave-uniform degree: one fully unrolled recursion per width
+#define LDPC_CASE(D)                                                \
+    case D:                                                         \
+    {                                                               \
+        double v[D];                                                \
+        _Pragma("unroll") for (int j = 0; j < D; ++j) v[j] = m[j];  \
+        if constexpr (RATIO)                                        \
+            cn_ratio<D>(v);                                         \
+        else                                                        \
+            cn_core<D, MINSUM>(v);                                  \
+        _Pragma("unroll") for (int j = 0; j < D; ++j) m[j] = v[j];  \
+        break;                                                      \
+    }
+    switch (degree)
+    {
+        LDPC_CASE(2)
+        LDPC_CASE(3)
+        LDPC_CASE(4)
+    default:
+        if constexpr (MAXD >= 6)
+            switch (degree)
+            {
+                LDPC_CASE(5)
+                LDPC_CASE(6)
+            default:
+                if constexpr (MAXD >= 8)
+                    switch (degree)
+                    {
+                        LDPC_CASE(7)
+                        LDPC_CASE(8)
+                    default: break;
+                    }
+                break;
+            }
+        break;
+    }
+#undef LDPC_CASE
+}
+
+__device__ __forceinline__ int wave_sum_i2(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ Reg2VnBlock load_vn_block(const Reg2VnBlock *table, uint32_t i) // {u32, u32, u32, u16, u16}
+{
+    static_assert(sizeof(Reg2VnBlock) == 16, "descriptor layout");
+    const auto t = uniform_table(reinterpret_cast<const uint32_t *>(table));
+    const uint32_t w0 = t[4 * i], w1 = t[4 * i + 1], w2 = t[4 * i + 2], w3 = t[4 * i + 3];
+    return Reg2VnBlock{w0, w1, w2, static_cast<uint16_t>(w3 & 0xFFFFu), static_cast<uint16_t>(w3 >> 16)};
+}
+
+// RATIO: the likelihood-ratio form of the sum-product iteration (detmath.h): c2v messages are lambda = e^-L, the
+// returned total is rho(total) = 1 / (lambda(L_ch) * prod lambda(c2v)) with the hard decision in its sign bit, the
+// owner's v2c is rho(total) * lambda(c2v_e); frames that leave the representable box go to a.redo_list.
+template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, int NV0, int NV1, bool RATIO>
+__global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, const DevReg2Plan R)
+{
+    static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
+    constexpr int W = NT / 64, NV = NV0 + NV1;
+    extern __shared__ double lds[]; // R.lds_entries doubles, then two vote words
+    const DevPlan &P = a.plan;
+    const int nc = P.nc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t *vote = reinterpret_cast<uint32_t *>(lds + R.lds_entries);
+    uint64_t frame = blockIdx.x;
+    if (a.redo_count_in) // second pass: only the frames the ratio form handed back
+    {
+        if (blockIdx.x >= *uniform_table(a.redo_count_in))
+            return;
+        frame = uniform_table(a.redo_list_in)[blockIdx.x];
+    }
+    double *llr = a.ws_llr + frame * nc;
+    uint8_t *hard = a.ws_hb + frame * nc;
+    const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
+
+    channel_init<NT>(a, frame, llr, tid);
+    if (tid == 0)
+    {
+        lds[R.neutral] = 1.0;
+        vote[0] = 0, vote[1] = 0, vote[2] = 0;
+    }
+    __syncthreads();
+    if (a.llr_in_dump)
+    {
+        double *o = a.llr_in_dump + frame * nc;
+        for (int r = tid; r < nc; r += NT)
+            o[P.rank_col[r]] = llr[r];
+    }
+
+    // ---- variable-node side: input LLRs (RATIO: as lambda = e^-L) into registers, first totals into LDS ----
+    // v2c initialisation (decoder.cpp:16-19): every edge starts with its VN's input LLR; with c2v = 0 (lambda = 1) in
+    // the owners' registers the first gather yields exactly that.
+    uint32_t escaped = 0; // RATIO: running maximum of dm_ratio_key over the checked values (detmath.h)
+    double lam[NV];
+    uint32_t vbits = 0; // hard decisions of this thread's variable nodes, bit i
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+    {
+        const Reg2VnBlock vb = load_vn_block(R.vn_blocks, i * W + wave);
+        lam[i] = RATIO ? 1.0 : 0.0;
+        if (lane < vb.count)
+        {
+            const double L = llr[R.vn_rank[(i * W + wave) * 64 + lane]];
+            if constexpr (RATIO)
+            {
+                if (!(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT))
+                    escaped = ~0u;
+                lam[i] = dm_exp_clamped(0.0 - L);
+                lds[vb.tot_off + lane] = dm_ratio_div(1.0, lam[i]);
+            }
+            else
+            {
+                lam[i] = L;
+                lds[vb.tot_off + lane] = L;
+            }
+        }
+    }
+
+    // ---- check-node side ----
+    double m[KC][MAXD];
+    uint32_t ew[KC][MAXD];
+    int deg[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+    {
+        deg[k] = R.cn_deg[k * W + wave];
+#pragma unroll
+        for (int j = 0; j < MAXD; ++j)
+        {
+            m[k][j] = RATIO ? 1.0 : 0.0;
+            ew[k][j] = R.edge_w[(k * MAXD + j) * NT + tid];
+        }
+    }
+    // which of this thread's edges go to the mailbox in round 0 / round 1 (bit k*MAXD+j).  The words are re-read through
+    // an opaque asm in every iteration: otherwise the compiler hoists all 2*KC*MAXD exec masks out of the loop into
+    // SGPR pairs and spills most of them
+    uint32_t rm0l = static_cast<uint32_t>(R.round0_mask[tid]), rm0h = static_cast<uint32_t>(R.round0_mask[tid] >> 32);
+    uint32_t rm1l = static_cast<uint32_t>(R.round1_mask[tid]), rm1h = static_cast<uint32_t>(R.round1_mask[tid] >> 32);
+    const char *lds_b = reinterpret_cast<const char *>(lds);
+    __syncthreads();
+
+    double *out_llr = WANT_LLR ? a.llr_out + frame * nc : nullptr;
+    uint32_t I = 0, result = 0;
+    for (;;)
+    {
+        asm volatile("" : "+v"(rm0l), "+v"(rm0h), "+v"(rm1l), "+v"(rm1h));
+        // ---- gather: v2c of every owned edge from its VN's total; syndrome of the decisions in the totals ----
+        uint32_t par = 0;
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+        {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int j = 0; j < MAXD; ++j)
+                if (j < deg[k])
+                {
+                    const double t = *reinterpret_cast<const double *>(lds_b + (ew[k][j] & 0x3FFF8u));
+                    if constexpr (RATIO)
+                    {
+                        pk ^= DM_SIGN_WORD(t);
+                        const double o = __builtin_fabs(t) * m[k][j]; // rho(total - c2v_e)
+                        DM_RATIO_TRACK(escaped, o);
+                        m[k][j] = o;
+                    }
+                    else
+                    {
+                        pk ^= (t <= 0) ? 0x80000000u : 0u;
+                        m[k][j] = t - m[k][j];
+                    }
+                }
+            par |= pk;
+        }
+        // ---- vote: escaped (ratio form) and syndrome (early termination); also the barrier that lets the scatter
+        //      below overwrite the position-0 entries the gather has just read ----
+        {
+            uint32_t f = (par >> 31) | ((RATIO && DM_RATIO_ESCAPED(escaped)) ? 2u : 0u);
+            const uint64_t any1 = __ballot(f & 1u), any2 = __ballot(f & 2u);
+            if (lane == 0 && (any1 | any2))
+                atomicOr(&vote[I & 1], (any1 ? 1u : 0u) | (any2 ? 2u : 0u));
+            __syncthreads();
+            const uint32_t v = vote[I & 1];
+            if (tid == 0)
+                vote[(I + 1) & 1] = 0;
+            if (RATIO && (v & 2u)) // checked before the syndrome: an escaped frame's decisions mean nothing
+            {
+                if (tid == 0)
+                    a.redo_list[atomicAdd(a.redo_count, 1u)] = static_cast<uint32_t>(frame);
+                return;
+            }
+            if (I > 0 && a.early_term && !(v & 1u)) // decoder.cpp:66-72: the decisions of iteration I-1 are a codeword
+            {
+                result = I - 1;
+                break;
+            }
+            if (I == a.iterations)
+            {
+                result = I;
+                break;
+            }
+        }
+        // ---- CN pass (decoder.cpp:25-45), entirely in registers; c2v of round-0 edges -> mailbox ----
+        [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+            ((deg[Ks] >= 2 ? cn_regs2<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks]) : void()), ...);
+        }(std::make_integer_sequence<int, KC>{});
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+#pragma unroll
+            for (int j = 0; j < MAXD; ++j)
+                if ((k * MAXD + j < 32 ? rm0l : rm0h) & (1u << ((k * MAXD + j) & 31)))
+                    lds[ew[k][j] >> 18] = m[k][j];
+        __syncthreads();
+        // ---- VN pass, APP and hard decision (decoder.cpp:48-64): totals of the two rounds ----
+        auto vn_round = [&]<int... Is>(std::integer_sequence<int, Is...>, auto base) {
+            (([&] {
+                 constexpr int i = decltype(base)::value + Is;
+                 const Reg2VnBlock vb = load_vn_block(R.vn_blocks, i * W + wave);
+                 if (lane < vb.count)
+                 {
+                     const double *c0 = lds + vb.p0_off + lane, *cr = lds + vb.prest_off + lane;
+                     if constexpr (RATIO)
+                     {
+                         // lambda(total) = lambda(L_ch) * prod lambda(c2v_p), in column file order
+                         double prod = lam[i] * c0[0];
+                         if (vb.degree <= 3)
+                             for (int p = 1; p < vb.degree; ++p)
+                                 prod *= cr[(p - 1) * vb.count];
+                         else
+                             for (int p = 1; p < vb.degree; ++p)
+                             {
+                                 prod *= cr[(p - 1) * vb.count];
+                                 if (p % 3 == 2)
+                                     DM_RATIO_TRACK(escaped, prod);
+                             }
+                         const uint32_t bit = prod >= 1.0; // total LLR <= 0
+                         const double tot = dm_ratio_div(1.0, prod); // rho(total)
+                         lds[vb.tot_off + lane] = dm_from_bits(dm_bits(tot) | (static_cast<uint64_t>(bit) << 63));
+                         vbits = (vbits & ~(1u << i)) | (bit << i);
+                         if constexpr (WANT_LLR)
+                             out_llr[P.rank_col[R.vn_rank[(i * W + wave) * 64 + lane]]] = 0.0 - dm_log(prod);
+                     }
+                     else
+                     {
+                         double out = lam[i] + c0[0]; // sequential sum in column file order
+                         for (int p = 1; p < vb.degree; ++p)
+                             out += cr[(p - 1) * vb.count];
+                         const uint32_t bit = out <= 0;
+                         lds[vb.tot_off + lane] = out;
+                         vbits = (vbits & ~(1u << i)) | (bit << i);
+                         if constexpr (WANT_LLR)
+                             out_llr[P.rank_col[R.vn_rank[(i * W + wave) * 64 + lane]]] = out;
+                     }
+                 }
+             }()),
+             ...);
+        };
+        vn_round(std::make_integer_sequence<int, NV0>{}, std::integral_constant<int, 0>{});
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+#pragma unroll
+            for (int j = 0; j < MAXD; ++j)
+                if ((k * MAXD + j < 32 ? rm1l : rm1h) & (1u << ((k * MAXD + j) & 31)))
+                    lds[ew[k][j] >> 18] = m[k][j];
+        __syncthreads();
+        vn_round(std::make_integer_sequence<int, NV1>{}, std::integral_constant<int, NV0>{});
+        __syncthreads();
+        ++I;
+    }
+
+    // ---- outputs ----
+    const bool ran = a.iterations > 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+    {
+        const Reg2VnBlock vb = load_vn_block(R.vn_blocks, i * W + wave);
+        if (lane < vb.count)
+            hard[R.vn_rank[(i * W + wave) * 64 + lane]] = ran ? ((vbits >> i) & 1u) : 0;
+    }
+    if (tid == 0)
+    {
+        vote[2] = 0;
+        if (a.iters)
+            a.iters[frame] = result;
+    }
+    __syncthreads(); // hard[] is read back below by other threads of this workgroup
+    if (a.hard)
+    {
+        uint8_t *h = a.hard + frame * nc;
+        for (int r = tid; r < nc; r += NT)
+            h[P.rank_col[r]] = hard[r];
+    }
+    if constexpr (WANT_LLR)
+    {
+        if (!ran)
+            for (int r = tid; r < nc; r += NT)
+                out_llr[P.rank_col[r]] = 0.0;
+    }
+    if (a.bit_errors)
+    {
+        int err = 0;
+        for (int i = tid; i < P.n_bitpos; i += NT)
+        {
+            int est = hard[P.tx_rank[i]];
+            int tx = cw ? static_cast<int>(cw[P.bit_pos[i]]) : 0;
+            err += est != tx;
+        }
+        err = wave_sum_i2(err);
+        if (lane == 0 && err)
+            atomicAdd(&vote[2], static_cast<uint32_t>(err));
+        __syncthreads();
+        if (tid == 0)
+            a.bit_errors[frame] = vote[2];
+    }
+}
+
+template <int NT, int KC, int MAXD, int NV0, int NV1>
+int launch_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, void *stream)
+{
+    const bool want_llr = a.llr_out != nullptr;
+    const bool ratio = a.redo_list != nullptr;
+    if (ratio && (min_sum || !a.early_term || a.iterations == 0 || !a.redo_count || a.redo_count_in))
+        return hipErrorInvalidValue;
+    void (*k)(const DecodeArgs, const DevReg2Plan) = nullptr;
+    if (min_sum)
+        k = want_llr ? decode_reg2_kernel<true, true, NT, KC, MAXD, NV0, NV1, false> : decode_reg2_kernel<true, false, NT, KC, MAXD, NV0, NV1, false>;
+    else if (ratio)
+        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true> : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true>;
+    else
+        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false> : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false>;
+    const uint32_t lds = r.lds_entries * 8u + 16u;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(a.n_frames)), dim3(NT), lds, static_cast<hipStream_t>(stream), a, r);
+    return hipGetLastError();
+}
+
+} // namespace
+
+int launch_decode_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, void *stream)
+{
+    if (a.n_frames == 0)
+        return hipSuccess;
+    if (!a.ws_llr || !a.ws_hb)
+        return hipErrorInvalidValue;
+    if (r.nt == 1024 && r.kc == 4 && r.maxd == 6 && r.nv0 == 4 && r.nv1 == 4)
+        return launch_reg2<1024, 4, 6, 4, 4>(a, r, min_sum, stream);
+    if (r.nt == 512 && r.kc == 8 && r.maxd == 6 && r.nv0 == 8 && r.nv1 == 8)
+        return launch_reg2<512, 8, 6, 8, 8>(a, r, min_sum, stream);
+    return hipErrorInvalidValue;
+}
+
+} // namespace ldpc_amd

@@ -229,4 +229,108 @@ RegPlan build_reg_plan(const LdpcCode &code, const Plan &plan, int nt, int kc, i
     return r;
 }
 
+// Register-resident decoder, second form (plan.hpp).  VN blocks are the Plan's (<= 64 equal-degree nodes, degree
+// descending); they are dealt to the two rounds so that both mailbox images have about the same number of entries.
+Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc, int maxd, int nv0, int nv1)
+{
+    Reg2Plan r;
+    r.nt = nt, r.kc = kc, r.maxd = maxd, r.nv0 = nv0, r.nv1 = nv1;
+    const int W = nt / kWaveSize, NT = nt;
+    const SparseGF2 &H = code.H;
+    const int n_cb = static_cast<int>(plan.cn_blocks.size()), n_vb = static_cast<int>(plan.vn_blocks.size());
+    if (code.min_cn_degree() < 2 || plan.max_cn_degree > maxd || n_cb > kc * W || plan.has_isolated_vn || kc * maxd > 64 ||
+        n_vb > W * (nv0 + nv1) || plan.nnz == 0)
+        return r;
+    const int cap[2] = {W * nv0, W * nv1};
+    std::vector<int> rb[2]; // Plan VN-block ids per round
+    long ent[2] = {0, 0};
+    for (int b = 0; b < n_vb; ++b)
+    {
+        const bool ok0 = static_cast<int>(rb[0].size()) < cap[0], ok1 = static_cast<int>(rb[1].size()) < cap[1];
+        const int rd = (ok0 && (!ok1 || ent[0] * cap[1] <= ent[1] * cap[0])) ? 0 : 1;
+        rb[rd].push_back(b);
+        ent[rd] += static_cast<long>(plan.vn_blocks[b].degree) * plan.vn_blocks[b].count;
+    }
+    // round 1: position-0 entries of all blocks first (64 per block: they receive the totals in place), then the rest
+    const uint32_t c0_area = static_cast<uint32_t>(rb[1].size()) * kWaveSize;
+    uint32_t e0 = 0, e1 = c0_area;
+    r.vn_blocks.assign(static_cast<size_t>(W) * (nv0 + nv1), Reg2VnBlock{0, 0, 0, 0, 0});
+    r.vn_rank.assign(static_cast<size_t>(W) * (nv0 + nv1) * kWaveSize, kNoSlot);
+    std::vector<uint32_t> edge_gather(plan.nnz), edge_scatter(plan.nnz);
+    std::vector<uint8_t> edge_round(plan.nnz);
+    std::vector<Reg2VnBlock *> placed[2];
+    for (int rd = 0; rd < 2; ++rd)
+        for (size_t q = 0; q < rb[rd].size(); ++q)
+        {
+            const VnBlock &vb = plan.vn_blocks[rb[rd][q]];
+            const size_t pos = (q / W + (rd ? nv0 : 0)) * W + q % W; // (i, wave)
+            Reg2VnBlock &o = r.vn_blocks[pos];
+            o.count = vb.count, o.degree = vb.degree;
+            if (rd == 0)
+            {
+                o.p0_off = e0, o.prest_off = e0 + vb.count;
+                o.tot_off = static_cast<uint32_t>(q) * kWaveSize; // + e_max, below
+                e0 += static_cast<uint32_t>(vb.degree) * vb.count;
+            }
+            else
+            {
+                o.p0_off = static_cast<uint32_t>(q) * kWaveSize, o.tot_off = o.p0_off;
+                o.prest_off = e1;
+                e1 += static_cast<uint32_t>(vb.degree - 1) * vb.count;
+            }
+            for (int l = 0; l < vb.count; ++l)
+                r.vn_rank[pos * kWaveSize + l] = vb.first + l;
+            placed[rd].push_back(&o);
+        }
+    r.e_max = (std::max(e0, e1) + 31u) & ~31u;
+    const uint32_t n_tot0 = static_cast<uint32_t>(rb[0].size()) * kWaveSize;
+    r.neutral = r.e_max + n_tot0;
+    r.lds_entries = r.neutral + 2;
+    if (r.e_max > 16383u || static_cast<size_t>(r.lds_entries) * 8 + 64 > 160 * 1024)
+        return r;
+    for (Reg2VnBlock *o : placed[0])
+        o->tot_off += r.e_max;
+    for (int rd = 0; rd < 2; ++rd)
+        for (size_t q = 0; q < rb[rd].size(); ++q)
+        {
+            const VnBlock &vb = plan.vn_blocks[rb[rd][q]];
+            const Reg2VnBlock &o = *placed[rd][q];
+            for (int l = 0; l < vb.count; ++l)
+            {
+                const int col = static_cast<int>(plan.rank_col[vb.first + l]);
+                for (int p = 0; p < vb.degree; ++p)
+                {
+                    const int e = H.cedge[H.cptr[col] + p];
+                    edge_gather[e] = o.tot_off + l;
+                    edge_scatter[e] = p == 0 ? o.p0_off + l : o.prest_off + static_cast<uint32_t>(p - 1) * vb.count + l;
+                    edge_round[e] = static_cast<uint8_t>(rd);
+                }
+            }
+        }
+    r.edge_w.assign(static_cast<size_t>(kc) * maxd * NT, r.neutral << 3);
+    r.round0_mask.assign(NT, 0), r.round1_mask.assign(NT, 0);
+    r.cn_deg.assign(static_cast<size_t>(kc) * W, 0), r.cn_cnt.assign(static_cast<size_t>(kc) * W, 0);
+    int rank = 0; // CN rank in the Plan's order (cn_rank_row), block by block
+    for (int bi = 0; bi < n_cb; ++bi)
+    {
+        const CnBlock &cb = plan.cn_blocks[bi];
+        const int k = bi / W, wave = bi % W;
+        r.cn_deg[k * W + wave] = static_cast<uint8_t>(cb.degree);
+        r.cn_cnt[k * W + wave] = static_cast<uint8_t>(cb.count);
+        for (int l = 0; l < cb.count; ++l, ++rank)
+        {
+            const int row = static_cast<int>(plan.cn_rank_row[rank]);
+            const int tid = wave * kWaveSize + l;
+            for (int j = 0; j < cb.degree; ++j)
+            {
+                const int e = H.redge[H.rptr[row] + j], s = k * maxd + j;
+                r.edge_w[static_cast<size_t>(s) * NT + tid] = (edge_gather[e] << 3) | (edge_scatter[e] << 18);
+                (edge_round[e] ? r.round1_mask : r.round0_mask)[tid] |= 1ull << s;
+            }
+        }
+    }
+    r.ok = true;
+    return r;
+}
+
 } // namespace ldpc_amd

@@ -106,7 +106,50 @@ struct RegPlan
     std::vector<uint32_t> round_first;      // [rounds+1] first VN block of each round
 };
 
+// ---- register-resident decoder, second form: totals come back instead of messages ---------------------------
+// One workgroup of nt threads (nt/64 waves) = one frame per CU.  Thread (wave, lane) owns the check nodes of CN blocks
+// k*(nt/64) + wave, k < kc, and keeps their messages in registers.  The thread that owns an edge also forms the edge's
+// v2c message: the variable node's thread returns only the node's TOTAL (decoder.cpp:50-56: out, or its likelihood
+// ratio), one entry per node instead of one per edge, and the hard decision travels in that entry's sign
+// (ratio form) or is read off it (LLR domain: out <= 0).  c2v messages reach the variable nodes through an LDS
+// mailbox of 8-byte entries in two rounds (the n=8192 code's 24576 messages exceed 160 KB):
+//
+//   entries [0, e_max)            mailbox: round 0 uses [0, E0), round 1 [0, E1); a VN block's column sits at
+//                                 p0_off + lane (position 0) and prest_off + (p-1)*count + lane (positions >= 1)
+//   entries [e_max, e_max + n0)   totals of the round-0 variable nodes (round-1 totals are written in place, over
+//                                 position 0 of their column, which nothing overwrites before the gather)
+//   entry   neutral               +1.0: what register columns without an edge gather
+//
+// Variable-node blocks are dealt to (round, i, wave): wave w handles blocks [(round, i, w)] for i < nv[round].
+
+struct Reg2VnBlock
+{
+    uint32_t p0_off;    // entry of (position 0, lane 0)
+    uint32_t prest_off; // entry of (position 1, lane 0)
+    uint32_t tot_off;   // entry the total of lane 0 is written to
+    uint16_t count;     // 0 = no block
+    uint16_t degree;
+};
+
+struct Reg2Plan
+{
+    bool ok = false;
+    int nt = 0, kc = 0, maxd = 0, nv0 = 0, nv1 = 0;
+    uint32_t e_max = 0, neutral = 0, lds_entries = 0;
+    // [(k*maxd + j)*nt + tid]: bits 0..17 = byte address the edge's VN total is gathered from,
+    // bits 18..31 = mailbox entry the edge's c2v message is scattered to
+    std::vector<uint32_t> edge_w;
+    std::vector<uint64_t> round0_mask; // [tid] bit k*maxd+j: the edge exists and its VN is a round-0 node
+    std::vector<uint64_t> round1_mask; // [tid] ... a round-1 node
+    std::vector<uint8_t> cn_deg;       // [k*(nt/64) + wave] degree of that CN block (0 = none)
+    std::vector<uint8_t> cn_cnt;       // [k*(nt/64) + wave] check nodes in the block
+    std::vector<Reg2VnBlock> vn_blocks; // [(i*(nt/64) + wave)], i < nv0 + nv1 (i < nv0: round 0)
+    std::vector<uint32_t> vn_rank;      // [(i*(nt/64) + wave)*64 + lane] VN rank of the Plan (kNoSlot = none)
+};
+
 Plan build_plan(const LdpcCode &code);
+// plan for the decode_reg2_kernel<nt, kc, maxd, nv0, nv1> instantiation; ok = false when the code does not fit it
+Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc, int maxd, int nv0, int nv1);
 // `nt` threads, `kc` x `maxd` register tile = the kernel instantiation to plan for; lds_budget = bytes of LDS
 // one workgroup may use for its mailbox
 RegPlan build_reg_plan(const LdpcCode &code, const Plan &plan, int nt, int kc, int maxd, uint32_t lds_budget);

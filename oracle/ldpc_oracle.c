@@ -432,7 +432,7 @@ static int is_codeword(const dec_t *d)
 static void cn_update_ratio(dec_t *d, const int *cn, int cw)
 {
     enum { MAXD = 64 };
-    double v[MAXD] = {0}, F[MAXD], B[MAXD];
+    double v[MAXD] = {0};
     for (int j = 0; j < cw; ++j)
         v[j] = d->v2c[cn[j]];
     if (cw == 2)
@@ -457,16 +457,29 @@ static void cn_update_ratio(dec_t *d, const int *cn, int cw)
     }
     else
     {
-        F[0] = v[0];
-        B[cw - 1] = v[cw - 1];
-        for (int j = 1; j <= cw - 3; ++j)
-            F[j] = dm_ratio_rho(F[j - 1], v[j]);
-        for (int j = cw - 2; j >= 2; --j)
-            B[j] = dm_ratio_rho(B[j + 1], v[j]);
-        d->c2v[cn[0]] = dm_ratio_lambda(B[2], v[1]);
-        d->c2v[cn[cw - 1]] = dm_ratio_lambda(F[cw - 3], v[cw - 2]);
-        for (int j = 1; j < cw - 1; ++j)
-            d->c2v[cn[j]] = dm_ratio_lambda(F[j - 1], B[j + 1]);
+        /* cw >= 5: partial results as undivided fractions (detmath.h, dm_frac), F[j] = inputs 0..j,
+           B[j] = inputs j..cw-1, rescaled when they cover an odd number >= 3 of inputs */
+        dm_frac Ff[MAXD], Bf[MAXD];
+        Ff[1] = dm_frac_first(v[0], v[1]);
+        Bf[cw - 2] = dm_frac_first(v[cw - 1], v[cw - 2]);
+        for (int j = 2; j <= cw - 3; ++j)
+        {
+            Ff[j] = dm_frac_step(Ff[j - 1], v[j]);
+            if ((j + 1) % 2 == 1)
+                Ff[j] = dm_frac_norm(Ff[j]);
+        }
+        for (int j = cw - 3; j >= 2; --j)
+        {
+            Bf[j] = dm_frac_step(Bf[j + 1], v[j]);
+            if ((cw - j) % 2 == 1)
+                Bf[j] = dm_frac_norm(Bf[j]);
+        }
+        d->c2v[cn[0]] = dm_ratio_lambda_frac(Bf[2].n, Bf[2].d, v[1]);
+        d->c2v[cn[1]] = dm_ratio_lambda_frac(Bf[2].n, Bf[2].d, v[0]);
+        d->c2v[cn[cw - 2]] = dm_ratio_lambda_frac(Ff[cw - 3].n, Ff[cw - 3].d, v[cw - 1]);
+        d->c2v[cn[cw - 1]] = dm_ratio_lambda_frac(Ff[cw - 3].n, Ff[cw - 3].d, v[cw - 2]);
+        for (int j = 2; j <= cw - 3; ++j)
+            d->c2v[cn[j]] = dm_frac_lambda2(Ff[j - 1], Bf[j + 1]);
     }
 }
 

@@ -294,11 +294,7 @@ Engine::Engine(const std::string &pc_file, const std::string &gen_file, int devi
         }
         // second form (totals come back instead of messages): preferred when the code fits its one instantiation
         if (reg_plan_.ok && !std::getenv("LDPC_AMD_NO_REG2"))
-        {
-            // 512 threads x 256 registers (two waves per SIMD, eight check nodes per thread) or 1024 x 128
-            const bool nt1024 = std::getenv("LDPC_AMD_REG2_NT1024") != nullptr;
-            reg2_plan_ = nt1024 ? build_reg2_plan(*code_, plan_, 1024, 4, 6, 4, 4) : build_reg2_plan(*code_, plan_, 512, 8, 6, 8, 8);
-        }
+            reg2_plan_ = build_reg2_plan(*code_, plan_, 1024, 4, 6, 4, 4);
     }
 }
 

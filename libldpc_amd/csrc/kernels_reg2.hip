@@ -23,6 +23,7 @@
 //   file order, syndrome src/decoding/decoder.h:47-64, channels src/sim/channel.cpp (device_channel.hpp).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <utility>
 
 #include "device_channel.hpp"
@@ -86,6 +87,14 @@ __device__ __forceinline__ int wave_sum_i2(int v)
     return v;
 }
 
+// LDS access by absolute byte address: the packed edge words hold addresses relative to the start of the workgroup's
+// LDS, which is where the kernel's only LDS object (the dynamic array) begins — checked once per launch below
+template <typename T>
+__device__ __forceinline__ T __attribute__((address_space(3))) *lds_abs(uint32_t byte_address)
+{
+    return (T __attribute__((address_space(3))) *)(byte_address);
+}
+
 __device__ __forceinline__ Reg2VnBlock load_vn_block(const Reg2VnBlock *table, uint32_t i) // {u32, u32, u32, u16, u16}
 {
     static_assert(sizeof(Reg2VnBlock) == 16, "descriptor layout");
@@ -97,23 +106,31 @@ __device__ __forceinline__ Reg2VnBlock load_vn_block(const Reg2VnBlock *table, u
 // RATIO: the likelihood-ratio form of the sum-product iteration (detmath.h): c2v messages are lambda = e^-L, the
 // returned total is rho(total) = 1 / (lambda(L_ch) * prod lambda(c2v)) with the hard decision in its sign bit, the
 // owner's v2c is rho(total) * lambda(c2v_e); frames that leave the representable box go to a.redo_list.
-template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, int NV0, int NV1, bool RATIO>
+template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, int NV0, int NV1, bool RATIO, bool REDO>
 __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, const DevReg2Plan R)
 {
     static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
+    static_assert(!(RATIO && REDO), "the second pass runs the LLR-domain form");
     constexpr int W = NT / 64, NV = NV0 + NV1;
     extern __shared__ double lds[]; // R.lds_entries doubles, then two vote words
     const DevPlan &P = a.plan;
     const int nc = P.nc;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t *vote = reinterpret_cast<uint32_t *>(lds + R.lds_entries);
-    uint64_t frame = blockIdx.x;
-    if (a.redo_count_in) // second pass: only the frames the ratio form handed back
+    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>((double __attribute__((address_space(3))) *)lds)) != 0)
+        __builtin_trap(); // the dynamic LDS array does not start at 0: the packed addresses would be wrong
+    // REDO: second pass over the frames the ratio form handed back (a.redo_list_in[0 .. *a.redo_count_in)); a small grid
+    // walks the list, so that the usual case — an empty list — costs a few hundred workgroups, not one per frame
+    uint32_t redo_slot = blockIdx.x, n_redo = 0;
+    if constexpr (REDO)
     {
-        if (blockIdx.x >= *uniform_table(a.redo_count_in))
+        n_redo = *uniform_table(a.redo_count_in);
+        if (redo_slot >= n_redo)
             return;
-        frame = uniform_table(a.redo_list_in)[blockIdx.x];
     }
+    for (;;)
+    {
+    const uint64_t frame = REDO ? static_cast<uint64_t>(uniform_table(a.redo_list_in)[redo_slot]) : blockIdx.x;
     double *llr = a.ws_llr + frame * nc;
     uint8_t *hard = a.ws_hb + frame * nc;
     const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
@@ -137,7 +154,6 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
     // the owners' registers the first gather yields exactly that.
     uint32_t escaped = 0; // RATIO: running maximum of dm_ratio_key over the checked values (detmath.h)
     double lam[NV];
-    uint32_t vbits = 0; // hard decisions of this thread's variable nodes, bit i
 #pragma unroll
     for (int i = 0; i < NV; ++i)
     {
@@ -181,14 +197,17 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
     // SGPR pairs and spills most of them
     uint32_t rm0l = static_cast<uint32_t>(R.round0_mask[tid]), rm0h = static_cast<uint32_t>(R.round0_mask[tid] >> 32);
     uint32_t rm1l = static_cast<uint32_t>(R.round1_mask[tid]), rm1h = static_cast<uint32_t>(R.round1_mask[tid] >> 32);
-    const char *lds_b = reinterpret_cast<const char *>(lds);
     __syncthreads();
 
     double *out_llr = WANT_LLR ? a.llr_out + frame * nc : nullptr;
     uint32_t I = 0, result = 0;
     for (;;)
     {
-        asm volatile("" : "+v"(rm0l), "+v"(rm0h), "+v"(rm1l), "+v"(rm1h));
+        // (the same for the two address fields of the packed edge words: hoisted, they would cost 2*KC*MAXD registers)
+        uint32_t gather_mask = 0x3FFF8u, scatter_shift = 15u, scatter_mask = 0x1FFF8u;
+        const Reg2VnBlock *vn_blocks = R.vn_blocks;
+        asm volatile("" : "+v"(rm0l), "+v"(rm0h), "+v"(rm1l), "+v"(rm1h), "+v"(gather_mask), "+v"(scatter_shift), "+v"(scatter_mask),
+                     "+s"(vn_blocks));
         // ---- gather: v2c of every owned edge from its VN's total; syndrome of the decisions in the totals ----
         uint32_t par = 0;
 #pragma unroll
@@ -197,23 +216,27 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
             uint32_t pk = 0;
 #pragma unroll
             for (int j = 0; j < MAXD; ++j)
-                if (j < deg[k])
+            {
+                // (no test on the node's degree here: columns without an edge gather the neutral entry, +1.0, and stay
+                // what they are; straight-line code lets all the loads of a thread be in flight together)
+                const double t = *lds_abs<const double>(ew[k][j] & gather_mask);
+                if constexpr (RATIO)
                 {
-                    const double t = *reinterpret_cast<const double *>(lds_b + (ew[k][j] & 0x3FFF8u));
-                    if constexpr (RATIO)
-                    {
-                        pk ^= DM_SIGN_WORD(t);
-                        const double o = __builtin_fabs(t) * m[k][j]; // rho(total - c2v_e)
-                        DM_RATIO_TRACK(escaped, o);
-                        m[k][j] = o;
-                    }
-                    else
-                    {
-                        pk ^= (t <= 0) ? 0x80000000u : 0u;
-                        m[k][j] = t - m[k][j];
-                    }
+                    pk ^= DM_SIGN_WORD(t);
+                    const double o = __builtin_fabs(t) * m[k][j]; // rho(total - c2v_e)
+                    DM_RATIO_TRACK(escaped, o);
+                    m[k][j] = o;
                 }
+                else
+                {
+                    pk ^= (t <= 0) ? 0x80000000u : 0u;
+                    m[k][j] = t - m[k][j];
+                }
+            }
             par |= pk;
+            // keep the loads of the next check node behind this one's arithmetic: all KC*MAXD totals in flight at once
+            // would need more registers than the thread has left beside its messages
+            asm volatile("" ::: "memory");
         }
         // ---- vote: escaped (ratio form) and syndrome (early termination); also the barrier that lets the scatter
         //      below overwrite the position-0 entries the gather has just read ----
@@ -252,21 +275,28 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
 #pragma unroll
             for (int j = 0; j < MAXD; ++j)
                 if ((k * MAXD + j < 32 ? rm0l : rm0h) & (1u << ((k * MAXD + j) & 31)))
-                    lds[ew[k][j] >> 18] = m[k][j];
+                    *lds_abs<double>((ew[k][j] >> scatter_shift) & scatter_mask) = m[k][j];
         __syncthreads();
         // ---- VN pass, APP and hard decision (decoder.cpp:48-64): totals of the two rounds ----
         auto vn_round = [&]<int... Is>(std::integer_sequence<int, Is...>, auto base) {
             (([&] {
                  constexpr int i = decltype(base)::value + Is;
-                 const Reg2VnBlock vb = load_vn_block(R.vn_blocks, i * W + wave);
+                 const Reg2VnBlock vb = load_vn_block(vn_blocks, i * W + wave);
                  if (lane < vb.count)
                  {
                      const double *c0 = lds + vb.p0_off + lane, *cr = lds + vb.prest_off + lane;
+                     double tot_entry, out_value;
                      if constexpr (RATIO)
                      {
                          // lambda(total) = lambda(L_ch) * prod lambda(c2v_p), in column file order
                          double prod = lam[i] * c0[0];
-                         if (vb.degree <= 3)
+                         if (vb.degree == 3) // the regular code's case, unrolled: all loads in flight at once
+                         {
+                             const double x1 = cr[0], x2 = cr[vb.count];
+                             prod *= x1;
+                             prod *= x2;
+                         }
+                         else if (vb.degree <= 3)
                              for (int p = 1; p < vb.degree; ++p)
                                  prod *= cr[(p - 1) * vb.count];
                          else
@@ -276,24 +306,30 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
                                  if (p % 3 == 2)
                                      DM_RATIO_TRACK(escaped, prod);
                              }
-                         const uint32_t bit = prod >= 1.0; // total LLR <= 0
+                         const uint64_t bit = prod >= 1.0; // total LLR <= 0: the decision rides in the sign of the entry
                          const double tot = dm_ratio_div(1.0, prod); // rho(total)
-                         lds[vb.tot_off + lane] = dm_from_bits(dm_bits(tot) | (static_cast<uint64_t>(bit) << 63));
-                         vbits = (vbits & ~(1u << i)) | (bit << i);
+                         tot_entry = dm_from_bits(dm_bits(tot) | (bit << 63));
                          if constexpr (WANT_LLR)
-                             out_llr[P.rank_col[R.vn_rank[(i * W + wave) * 64 + lane]]] = 0.0 - dm_log(prod);
+                             out_value = 0.0 - dm_log(prod);
                      }
                      else
                      {
                          double out = lam[i] + c0[0]; // sequential sum in column file order
-                         for (int p = 1; p < vb.degree; ++p)
-                             out += cr[(p - 1) * vb.count];
-                         const uint32_t bit = out <= 0;
-                         lds[vb.tot_off + lane] = out;
-                         vbits = (vbits & ~(1u << i)) | (bit << i);
-                         if constexpr (WANT_LLR)
-                             out_llr[P.rank_col[R.vn_rank[(i * W + wave) * 64 + lane]]] = out;
+                         if (vb.degree == 3)
+                         {
+                             const double x1 = cr[0], x2 = cr[vb.count];
+                             out += x1;
+                             out += x2;
+                         }
+                         else
+                             for (int p = 1; p < vb.degree; ++p)
+                                 out += cr[(p - 1) * vb.count];
+                         tot_entry = out;
+                         out_value = out;
                      }
+                     lds[vb.tot_off + lane] = tot_entry;
+                     if constexpr (WANT_LLR)
+                         out_llr[P.rank_col[R.vn_rank[(i * W + wave) * 64 + lane]]] = out_value;
                  }
              }()),
              ...);
@@ -305,7 +341,7 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
 #pragma unroll
             for (int j = 0; j < MAXD; ++j)
                 if ((k * MAXD + j < 32 ? rm1l : rm1h) & (1u << ((k * MAXD + j) & 31)))
-                    lds[ew[k][j] >> 18] = m[k][j];
+                    *lds_abs<double>((ew[k][j] >> scatter_shift) & scatter_mask) = m[k][j];
         __syncthreads();
         vn_round(std::make_integer_sequence<int, NV1>{}, std::integral_constant<int, NV0>{});
         __syncthreads();
@@ -319,7 +355,12 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
     {
         const Reg2VnBlock vb = load_vn_block(R.vn_blocks, i * W + wave);
         if (lane < vb.count)
-            hard[R.vn_rank[(i * W + wave) * 64 + lane]] = ran ? ((vbits >> i) & 1u) : 0;
+        {
+            // the totals of the last VN pass are still in LDS: the decision is the entry's sign (ratio form) or out <= 0
+            const double t = lds[vb.tot_off + lane];
+            const uint32_t bit = RATIO ? (DM_SIGN_WORD(t) >> 31) : (t <= 0);
+            hard[R.vn_rank[(i * W + wave) * 64 + lane]] = ran ? bit : 0;
+        }
     }
     if (tid == 0)
     {
@@ -356,6 +397,16 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
         if (tid == 0)
             a.bit_errors[frame] = vote[2];
     }
+    if constexpr (!REDO)
+        break;
+    else
+    {
+        redo_slot += gridDim.x;
+        if (redo_slot >= n_redo)
+            break;
+        __syncthreads(); // the next frame re-initialises the LDS words this one may still be reading
+    }
+    } // frame loop (one pass unless REDO)
 }
 
 template <int NT, int KC, int MAXD, int NV0, int NV1>
@@ -365,19 +416,25 @@ int launch_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, void *s
     const bool ratio = a.redo_list != nullptr;
     if (ratio && (min_sum || !a.early_term || a.iterations == 0 || !a.redo_count || a.redo_count_in))
         return hipErrorInvalidValue;
+    const bool redo = a.redo_count_in != nullptr;
+    if (redo && (min_sum || !a.redo_list_in))
+        return hipErrorInvalidValue;
     void (*k)(const DecodeArgs, const DevReg2Plan) = nullptr;
     if (min_sum)
-        k = want_llr ? decode_reg2_kernel<true, true, NT, KC, MAXD, NV0, NV1, false> : decode_reg2_kernel<true, false, NT, KC, MAXD, NV0, NV1, false>;
+        k = want_llr ? decode_reg2_kernel<true, true, NT, KC, MAXD, NV0, NV1, false, false> : decode_reg2_kernel<true, false, NT, KC, MAXD, NV0, NV1, false, false>;
     else if (ratio)
-        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true> : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true>;
+        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true, false> : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true, false>;
+    else if (redo)
+        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, true> : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, true>;
     else
-        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false> : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false>;
+        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, false> : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, false>;
+    const unsigned grid = redo ? static_cast<unsigned>(std::min<uint64_t>(a.n_frames, 512)) : static_cast<unsigned>(a.n_frames);
     const uint32_t lds = r.lds_entries * 8u + 16u;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(a.n_frames)), dim3(NT), lds, static_cast<hipStream_t>(stream), a, r);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, static_cast<hipStream_t>(stream), a, r);
     return hipGetLastError();
 }
 
@@ -391,8 +448,7 @@ int launch_decode_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, 
         return hipErrorInvalidValue;
     if (r.nt == 1024 && r.kc == 4 && r.maxd == 6 && r.nv0 == 4 && r.nv1 == 4)
         return launch_reg2<1024, 4, 6, 4, 4>(a, r, min_sum, stream);
-    if (r.nt == 512 && r.kc == 8 && r.maxd == 6 && r.nv0 == 8 && r.nv1 == 8)
-        return launch_reg2<512, 8, 6, 8, 8>(a, r, min_sum, stream);
+    // (512 threads x 256 registers, launch_reg2<512, 8, 6, 8, 8>, was measured 1.25x slower on the n=8192 code)
     return hipErrorInvalidValue;
 }
 

@@ -259,6 +259,7 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
     std::vector<uint32_t> edge_gather(plan.nnz), edge_scatter(plan.nnz);
     std::vector<uint8_t> edge_round(plan.nnz);
     std::vector<Reg2VnBlock *> placed[2];
+    std::vector<size_t> placed_pos[2];
     for (int rd = 0; rd < 2; ++rd)
         for (size_t q = 0; q < rb[rd].size(); ++q)
         {
@@ -278,9 +279,8 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
                 o.prest_off = e1;
                 e1 += static_cast<uint32_t>(vb.degree - 1) * vb.count;
             }
-            for (int l = 0; l < vb.count; ++l)
-                r.vn_rank[pos * kWaveSize + l] = vb.first + l;
             placed[rd].push_back(&o);
+            placed_pos[rd].push_back(pos);
         }
     r.e_max = (std::max(e0, e1) + 31u) & ~31u;
     const uint32_t n_tot0 = static_cast<uint32_t>(rb[0].size()) * kWaveSize;
@@ -290,23 +290,105 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
         return r;
     for (Reg2VnBlock *o : placed[0])
         o->tot_off += r.e_max;
+
+    // ---- which variable node sits in which (block, lane) ----
+    // Every offset above is a multiple of 32 entries plus the lane (full blocks), so the LDS bank of a node's total
+    // (gathered by the owners of its edges: ds_read_b64, 32 lanes per LDS cycle, bank = entry mod 32) and of its
+    // column entries (scattered to: ds_write_b64, 16 lanes per cycle, bank = entry mod 16) is its lane mod 32 / mod 16.
+    // The check-node side reads and writes in fixed lane groups — the j-th edges of 32 (16) neighbouring check nodes —
+    // so nodes are placed greedily where their lane collides least with the nodes already placed in the same groups
+    // (same degree class only: blocks are uniform in degree).  Natural order costs 3.5 LDS cycles per gather group
+    // and 2.2 per scatter group on the (3,6) n=8192 code; this placement 2.0 and 1.15.
+    struct Slot { uint32_t rd, q, lane; };
+    const int max_deg = plan.max_vn_degree;
+    std::vector<std::vector<std::vector<Slot>>> free_slots(max_deg + 1, std::vector<std::vector<Slot>>(64)); // [degree][rd*32 + colour]
     for (int rd = 0; rd < 2; ++rd)
-        for (size_t q = 0; q < rb[rd].size(); ++q)
+        for (size_t q = rb[rd].size(); q-- > 0;)
         {
             const VnBlock &vb = plan.vn_blocks[rb[rd][q]];
-            const Reg2VnBlock &o = *placed[rd][q];
-            for (int l = 0; l < vb.count; ++l)
+            for (uint32_t l = vb.count; l-- > 0;)
+                free_slots[vb.degree][rd * 32 + l % 32].push_back(Slot{static_cast<uint32_t>(rd), static_cast<uint32_t>(q), l});
+        }
+    // lane groups of the check-node side: edge -> (gather group, scatter group)
+    const uint32_t n_gg = static_cast<uint32_t>(kc) * maxd * W * 2, n_sg = static_cast<uint32_t>(kc) * maxd * W * 4;
+    std::vector<uint32_t> edge_gg(plan.nnz), edge_sg(plan.nnz);
+    {
+        int crank = 0;
+        for (int bi = 0; bi < n_cb; ++bi)
+        {
+            const CnBlock &cb = plan.cn_blocks[bi];
+            for (int l = 0; l < cb.count; ++l, ++crank)
             {
-                const int col = static_cast<int>(plan.rank_col[vb.first + l]);
-                for (int p = 0; p < vb.degree; ++p)
+                const int row = static_cast<int>(plan.cn_rank_row[crank]);
+                for (int j = 0; j < cb.degree; ++j)
                 {
-                    const int e = H.cedge[H.cptr[col] + p];
-                    edge_gather[e] = o.tot_off + l;
-                    edge_scatter[e] = p == 0 ? o.p0_off + l : o.prest_off + static_cast<uint32_t>(p - 1) * vb.count + l;
-                    edge_round[e] = static_cast<uint8_t>(rd);
+                    const int e = H.redge[H.rptr[row] + j];
+                    const uint32_t inst = static_cast<uint32_t>(bi) * maxd + j; // one wave instruction
+                    edge_gg[e] = inst * 2 + l / 32;
+                    edge_sg[e] = inst * 4 + l / 16;
                 }
             }
         }
+    }
+    std::vector<uint16_t> g_cnt(static_cast<size_t>(n_gg) * 32, 0), s_cnt(static_cast<size_t>(n_sg) * 2 * 16, 0);
+    std::vector<uint32_t> order(plan.nc);
+    std::iota(order.begin(), order.end(), 0u);
+    uint64_t rng = 0x9E3779B97F4A7C15ull; // fixed seed: the plan is a pure function of the code
+    for (size_t i = order.size(); i > 1; --i)
+    {
+        rng ^= rng >> 12, rng ^= rng << 25, rng ^= rng >> 27;
+        std::swap(order[i - 1], order[(rng * 0x2545F4914F6CDD1Dull >> 33) % i]);
+    }
+    std::vector<Slot> rank_slot(plan.nc);
+    for (uint32_t rank : order)
+    {
+        const int col = static_cast<int>(plan.rank_col[rank]);
+        const int d = H.cptr[col + 1] - H.cptr[col];
+        long best = -1;
+        int best_class = -1;
+        for (int cls = 0; cls < 64; ++cls)
+        {
+            if (free_slots[d][cls].empty())
+                continue;
+            const int rd = cls / 32, colour = cls % 32;
+            long cost = 0;
+            for (int p = 0; p < d; ++p)
+            {
+                const int e = H.cedge[H.cptr[col] + p];
+                cost += 4l * g_cnt[static_cast<size_t>(edge_gg[e]) * 32 + colour] +
+                        s_cnt[(static_cast<size_t>(edge_sg[e]) * 2 + rd) * 16 + colour % 16];
+            }
+            cost = cost * 4096 + static_cast<long>(4096 - free_slots[d][cls].size()); // ties: the emptiest class
+            if (best < 0 || cost < best)
+                best = cost, best_class = cls;
+        }
+        if (best_class < 0)
+            return r; // cannot happen: the slots of a degree class equal its nodes
+        const Slot sl = free_slots[d][best_class].back();
+        free_slots[d][best_class].pop_back();
+        rank_slot[rank] = sl;
+        for (int p = 0; p < d; ++p)
+        {
+            const int e = H.cedge[H.cptr[col] + p];
+            ++g_cnt[static_cast<size_t>(edge_gg[e]) * 32 + best_class % 32];
+            ++s_cnt[(static_cast<size_t>(edge_sg[e]) * 2 + best_class / 32) * 16 + (best_class % 32) % 16];
+        }
+    }
+    for (uint32_t rank = 0; rank < static_cast<uint32_t>(plan.nc); ++rank)
+    {
+        const Slot sl = rank_slot[rank];
+        const Reg2VnBlock &o = *placed[sl.rd][sl.q];
+        r.vn_rank[placed_pos[sl.rd][sl.q] * kWaveSize + sl.lane] = rank;
+        const int col = static_cast<int>(plan.rank_col[rank]);
+        const int d = H.cptr[col + 1] - H.cptr[col];
+        for (int p = 0; p < d; ++p)
+        {
+            const int e = H.cedge[H.cptr[col] + p];
+            edge_gather[e] = o.tot_off + sl.lane;
+            edge_scatter[e] = p == 0 ? o.p0_off + sl.lane : o.prest_off + static_cast<uint32_t>(p - 1) * o.count + sl.lane;
+            edge_round[e] = static_cast<uint8_t>(sl.rd);
+        }
+    }
     r.edge_w.assign(static_cast<size_t>(kc) * maxd * NT, r.neutral << 3);
     r.round0_mask.assign(NT, 0), r.round1_mask.assign(NT, 0);
     r.cn_deg.assign(static_cast<size_t>(kc) * W, 0), r.cn_cnt.assign(static_cast<size_t>(kc) * W, 0);

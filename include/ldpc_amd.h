@@ -151,6 +151,14 @@ int ldpc_hip_mt64(ldpc_hip_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, 
    the IEEE division; *mismatches receives the number of pairs whose quotients differ in any bit (expected: 0) */
 int ldpc_hip_selftest_division(ldpc_hip_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *mismatches);
 
+/* the kernels' arithmetic, element by element, for tests that hold it against libm and extended-precision host values
+   rather than against the same header compiled for the host: out[i] = fn(a[i] [, b[i]]) for the scalar functions
+   (fn 0..9: dm_exp, dm_log, dm_boxplus, dm_ratio_div, dm_ratio_rho, dm_ratio_lambda, dm_e_combine, dm_exp_clamped,
+   dm_boxplus_exp, dm_boxplus_log of libldpc_amd/csrc/detmath.h), out[i][0..D) = check-node update of the row
+   a[i][0..D) for fn 10..14 (likelihood-ratio form, D = 3, 4, 5, 6, 8) and fn 15, 16 (LLR domain, D = 4, 6).
+   a, b, out are HOST buffers of n (x D) doubles; b may be NULL for one-operand functions. */
+int ldpc_hip_selftest_math(ldpc_hip_ctx *ctx, int fn, uint64_t n, const double *a, const double *b, double *out);
+
 /* host-only self-test of the noise stream's chunk-state table bookkeeping (no GPU needed): replays n_requests sequential
    generate requests of chunks_per_request chunks each, starting at chunk first_chunk, and returns the largest table row
    any step reads or writes (must be <= 8192, the last row of the table), or UINT64_MAX if a request was left without a

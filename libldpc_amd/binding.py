@@ -79,6 +79,8 @@ def load_library(path=LIB_PATH):
     L.ldpc_hip_set_profiling.argtypes = [vp, i32]
     L.ldpc_hip_last_ms.restype = ct.c_float
     L.ldpc_hip_last_ms.argtypes = [vp, i32]
+    L.ldpc_hip_selftest_math.restype = i32
+    L.ldpc_hip_selftest_math.argtypes = [vp, i32, u64, vp, vp, vp]
     L.ldpc_hip_selftest_chunk_table.restype = u64
     L.ldpc_hip_selftest_chunk_table.argtypes = [u64, u64, u64]
     L.ldpc_hip_simulate.restype = i32
@@ -201,6 +203,19 @@ class HipDecoder:
         self._check(self.lib.ldpc_hip_selftest_division(self.ctx, int(n), int(seed), ct.byref(bad)),
                     "ldpc_hip_selftest_division")
         return bad.value
+
+    MATH_FNS = ("exp", "log", "boxplus", "ratio_div", "ratio_rho", "ratio_lambda", "e_combine", "exp_clamped", "boxplus_exp",
+                "boxplus_log", "cn_ratio3", "cn_ratio4", "cn_ratio5", "cn_ratio6", "cn_ratio8", "cn_llr4", "cn_llr6")
+
+    def selftest_math(self, fn, a, b=None):
+        """The device arithmetic of detmath.h / device_cn.hpp on host arrays: fn is a name of MATH_FNS."""
+        a = np.ascontiguousarray(a, np.float64)
+        out = np.empty_like(a)
+        n = a.shape[0]
+        bb = None if b is None else np.ascontiguousarray(b, np.float64)
+        self._check(self.lib.ldpc_hip_selftest_math(self.ctx, self.MATH_FNS.index(fn), n, _ptr(a), _ptr(bb), _ptr(out)),
+                    "ldpc_hip_selftest_math")
+        return out
 
     def mt64(self, seed, first, n):
         out = np.zeros(int(n), np.uint64)

@@ -345,6 +345,30 @@ int ldpc_hip_selftest_division(ldpc_hip_ctx *ctx, uint64_t n, uint64_t seed, uin
     });
 }
 
+int ldpc_hip_selftest_math(ldpc_hip_ctx *ctx, int fn, uint64_t n, const double *a, const double *b, double *out)
+{
+    return guarded([&] {
+        if (ldpc_hip_device_count() <= ctx->eng->device())
+            throw std::runtime_error("no usable HIP device (MI355X required)");
+        if (hipSetDevice(ctx->eng->device()) != hipSuccess)
+            throw std::runtime_error("hipSetDevice failed");
+        const int w = ldpc_amd::math_selftest_width(fn);
+        if (w == 0 || !a || !out)
+            throw std::runtime_error("ldpc_hip_selftest_math: unknown function or null buffer");
+        const size_t bytes = 8 * n * static_cast<size_t>(w);
+        double *da = nullptr, *db = nullptr, *dout = nullptr;
+        bool ok = hipMalloc(&da, bytes) == hipSuccess && hipMalloc(&dout, bytes) == hipSuccess &&
+                  hipMemcpy(da, a, bytes, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok && b)
+            ok = hipMalloc(&db, bytes) == hipSuccess && hipMemcpy(db, b, bytes, hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && ldpc_amd::launch_math_selftest(fn, n, da, db ? db : da, dout, nullptr) == hipSuccess &&
+             hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(da), (void)hipFree(db), (void)hipFree(dout);
+        if (!ok)
+            throw std::runtime_error("ldpc_hip_selftest_math failed to run");
+    });
+}
+
 uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per_request, uint64_t n_requests)
 {
     // host-only replay of MtStream's table bookkeeping: sequential requests, as a long Monte-Carlo run issues them

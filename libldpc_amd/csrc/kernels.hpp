@@ -193,4 +193,29 @@ int launch_batch_counters(const uint32_t *iters, const uint32_t *bit_errors, uin
 // dm_ratio_div vs the IEEE division on n pseudo-random operand pairs; *mismatches (device, zeroed by the caller)
 int launch_division_selftest(uint64_t n, uint64_t seed, unsigned long long *mismatches, void *stream);
 
+// functions of detmath.h / device_cn.hpp evaluated element by element (include/ldpc_amd.h: ldpc_hip_selftest_math)
+enum MathFn : int
+{
+    kMathExp = 0,       // dm_exp(a)
+    kMathLog,           // dm_log(a)
+    kMathBoxplus,       // dm_boxplus(a, b)
+    kMathRatioDiv,      // dm_ratio_div(a, b)
+    kMathRatioRho,      // dm_ratio_rho(a, b)
+    kMathRatioLambda,   // dm_ratio_lambda(a, b)
+    kMathECombine,      // dm_e_combine(a, b)
+    kMathExpClamped,    // dm_exp_clamped(a)
+    kMathBoxplusExp,    // dm_boxplus_exp(a)
+    kMathBoxplusLog,    // dm_boxplus_log(a)
+    kMathCnRatio3,      // cn_ratio<3> on rows a[i][3] -> out[i][3]
+    kMathCnRatio4,
+    kMathCnRatio5,
+    kMathCnRatio6,
+    kMathCnRatio8,
+    kMathCnLlr4,        // cn_core<4, sum-product> (LLR domain, E-form recursion)
+    kMathCnLlr6,
+    kMathCount
+};
+int math_selftest_width(int fn); // values per element in a / out (0 = unknown function)
+int launch_math_selftest(int fn, uint64_t n, const double *a, const double *b, double *out, void *stream);
+
 } // namespace ldpc_amd

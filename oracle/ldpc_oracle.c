@@ -483,6 +483,145 @@ static void cn_update_ratio(dec_t *d, const int *cn, int cw)
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Element-by-element arithmetic for tests/test_gpu_math.py (same function numbering as MathFn in
+ * libldpc_amd/csrc/kernels.hpp).
+ *   orc_math_ref: what the function MEANS, computed without detmath.h — glibc libm in binary64 for exp / log / the
+ *                 reference's jacobian expression (decoder.h:12-15), x87 extended precision (long double) for the
+ *                 rational expressions, the plain divided forward/backward recursion of decoder.cpp:31-44 in long
+ *                 double for the check-node updates.
+ *   orc_math_det: detmath.h compiled for the host (the det-mode oracle's arithmetic).
+ * ------------------------------------------------------------------------------------------------ */
+static double ref_jacobian(double x, double y) /* decoder.h:12-15, libm */
+{
+    int sx = 1 - 2 * (signbit(x) != 0), sy = 1 - 2 * (signbit(y) != 0);
+    double ax = fabs(x), ay = fabs(y);
+    double mn = ay < ax ? ay : ax;
+    return (double)(sx * sy) * mn + log((1 + exp(-fabs(x + y))) / (1 + exp(-fabs(x - y))));
+}
+
+static void ref_cn_ratio_ld(int cw, const double *v, double *out) /* rho in, lambda out; divided at every step */
+{
+    long double F[16], B[16];
+    F[0] = v[0], B[cw - 1] = v[cw - 1];
+    for (int j = 1; j < cw; ++j)
+    {
+        F[j] = (1.0L + F[j - 1] * (long double)v[j]) / (F[j - 1] + (long double)v[j]);
+        B[cw - 1 - j] = (1.0L + B[cw - j] * (long double)v[cw - 1 - j]) / (B[cw - j] + (long double)v[cw - 1 - j]);
+    }
+    out[0] = (double)(1.0L / B[1]);
+    out[cw - 1] = (double)(1.0L / F[cw - 2]);
+    for (int j = 1; j < cw - 1; ++j)
+        out[j] = (double)((F[j - 1] + B[j + 1]) / (1.0L + F[j - 1] * B[j + 1]));
+}
+
+static void ref_cn_llr(int cw, const double *v, double *out) /* decoder.cpp:31-44 with the libm jacobian */
+{
+    double F[16], B[16];
+    F[0] = v[0], B[cw - 1] = v[cw - 1];
+    for (int j = 1; j < cw; ++j)
+    {
+        F[j] = ref_jacobian(F[j - 1], v[j]);
+        B[cw - 1 - j] = ref_jacobian(B[cw - j], v[cw - j - 1]);
+    }
+    out[0] = B[1], out[cw - 1] = F[cw - 2];
+    for (int j = 1; j < cw - 1; ++j)
+        out[j] = ref_jacobian(F[j - 1], B[j + 1]);
+}
+
+static int math_width(int fn)
+{
+    static const int w[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 3, 4, 5, 6, 8, 4, 6};
+    return fn >= 0 && fn < (int)(sizeof w / sizeof w[0]) ? w[fn] : 0;
+}
+
+int orc_math_ref(int fn, uint64_t n, const double *a, const double *b, double *out)
+{
+    const int w = math_width(fn);
+    if (!w)
+        return -1;
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        long double x = a[i * w], y = b ? b[i * w] : 0;
+        switch (fn)
+        {
+        case 0: out[i] = exp(a[i]); break;
+        case 1: out[i] = log(a[i]); break;
+        case 2: out[i] = ref_jacobian(a[i], b[i]); break;
+        case 3: out[i] = a[i] / b[i]; break;
+        case 4: out[i] = (double)((1.0L + x * y) / (x + y)); break;
+        case 5: out[i] = (double)((x + y) / (1.0L + x * y)); break;
+        case 6: out[i] = (double)((x + y) / (1.0L + x * y)); break;
+        case 7: out[i] = exp(fmin(fmax(a[i], -700.0), 700.0)); break;
+        case 8: out[i] = exp(-fmin(a[i], 700.0)); break;
+        case 9: out[i] = log(a[i]); break;
+        case 15: case 16: ref_cn_llr(w, a + i * w, out + i * w); break;
+        default: ref_cn_ratio_ld(w, a + i * w, out + i * w); break;
+        }
+    }
+    return 0;
+}
+
+static void det_cn_ratio(int cw, const double *v, double *out)
+{
+    dec_t d;
+    double v2c[16], c2v[16];
+    int cn[16];
+    for (int j = 0; j < cw; ++j)
+        v2c[j] = v[j], cn[j] = j;
+    d.v2c = v2c, d.c2v = c2v;
+    cn_update_ratio(&d, cn, cw);
+    for (int j = 0; j < cw; ++j)
+        out[j] = c2v[j];
+}
+
+int orc_math_det(int fn, uint64_t n, const double *a, const double *b, double *out)
+{
+    const int w = math_width(fn);
+    if (!w)
+        return -1;
+    for (uint64_t i = 0; i < n; ++i)
+        switch (fn)
+        {
+        case 0: out[i] = dm_exp(a[i]); break;
+        case 1: out[i] = dm_log(a[i]); break;
+        case 2: out[i] = dm_boxplus(a[i], b[i]); break;
+        case 3: out[i] = dm_ratio_div(a[i], b[i]); break;
+        case 4: out[i] = dm_ratio_rho(a[i], b[i]); break;
+        case 5: out[i] = dm_ratio_lambda(a[i], b[i]); break;
+        case 6: out[i] = dm_e_combine(a[i], b[i]); break;
+        case 7: out[i] = dm_exp_clamped(a[i]); break;
+        case 8: out[i] = dm_boxplus_exp(a[i]); break;
+        case 9: out[i] = dm_boxplus_log(a[i]); break;
+        case 15: case 16:
+        {
+            dec_t d;
+            double v2c[16], c2v[16], F[16], B[16];
+            int cn[16];
+            for (int j = 0; j < w; ++j)
+                v2c[j] = a[i * w + j], cn[j] = j;
+            d.v2c = v2c, d.c2v = c2v, d.F = F, d.B = B, d.cn = jacobian_det;
+            if (!cn_update_det_shared(&d, cn, w))
+            {
+                F[0] = v2c[0], B[w - 1] = v2c[w - 1];
+                for (int j = 1; j < w; ++j)
+                {
+                    F[j] = jacobian_det(F[j - 1], v2c[j]);
+                    B[w - 1 - j] = jacobian_det(B[w - j], v2c[w - j - 1]);
+                }
+                c2v[0] = B[1], c2v[w - 1] = F[w - 2];
+                for (int j = 1; j < w - 1; ++j)
+                    c2v[j] = jacobian_det(F[j - 1], B[j + 1]);
+            }
+            for (int j = 0; j < w; ++j)
+                out[i * w + j] = c2v[j];
+            break;
+        }
+        default: det_cn_ratio(w, a + i * w, out + i * w); break;
+        }
+    return 0;
+}
+
 static int dec_decode_ratio(dec_t *d)
 {
     const spm *H = &d->code->H;

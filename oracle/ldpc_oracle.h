@@ -122,6 +122,10 @@ int orc_simulate(const orc_code *c, int chan_type, uint64_t seed, const double x
 void orc_mt64_stream(uint64_t seed, uint64_t n, uint64_t *out);
 double orc_exp(int math_mode, double x);
 double orc_log(int math_mode, double x);
+/* element-by-element arithmetic for tests/test_gpu_math.py: what each function means (libm / long double), and
+   detmath.h compiled for the host; fn as MathFn in libldpc_amd/csrc/kernels.hpp; 0 on success */
+int orc_math_ref(int fn, uint64_t n, const double *a, const double *b, double *out);
+int orc_math_det(int fn, uint64_t n, const double *a, const double *b, double *out);
 
 #ifdef __cplusplus
 }

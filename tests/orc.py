@@ -65,6 +65,8 @@ def lib():
     L.orc_ratio_stats.argtypes = [vp, vp, i32]
     L.orc_exp.restype, L.orc_exp.argtypes = dbl, [i32, dbl]
     L.orc_log.restype, L.orc_log.argtypes = dbl, [i32, dbl]
+    for f in (L.orc_math_ref, L.orc_math_det):
+        f.restype, f.argtypes = i32, [i32, u64, vp, vp, vp]
     _lib = L
     return L
 
@@ -212,3 +214,70 @@ def ref_dump(h, g, chan, dec, iters, early, seed, x, skip, count, tmp):
                     ("llr_out", "<f8", (nc,)), ("codeword", "u1", (nc,))])
     a = np.frombuffer(raw, rec, cnt, 8)
     return {k: np.ascontiguousarray(a[k]) for k in rec.names}
+
+
+MATH_FNS = ("exp", "log", "boxplus", "ratio_div", "ratio_rho", "ratio_lambda", "e_combine", "exp_clamped", "boxplus_exp",
+            "boxplus_log", "cn_ratio3", "cn_ratio4", "cn_ratio5", "cn_ratio6", "cn_ratio8", "cn_llr4", "cn_llr6")
+
+
+def math_eval(fn, a, b=None, det=False):
+    """out = fn(a[, b]) element by element: det=False -> what the function means (glibc libm / long double, no
+    detmath.h), det=True -> detmath.h compiled for the host."""
+    a = np.ascontiguousarray(a, np.float64)
+    bb = None if b is None else np.ascontiguousarray(b, np.float64)
+    out = np.empty_like(a)
+    f = lib().orc_math_det if det else lib().orc_math_ref
+    assert f(MATH_FNS.index(fn), a.shape[0], _p(a), _p(bb), _p(out)) == 0
+    return out
+
+
+def math_points(fn, n, seed):
+    """Deterministic operands for `fn`: (a, b or None).  Covers the whole domain the kernels use each function on,
+    with the edges of the representable boxes (|L| = 166, 600, 700, 709) and special operands mixed in."""
+    rng = np.random.default_rng([seed, MATH_FNS.index(fn)])
+    def mix(parts):
+        x = np.concatenate(parts)
+        rng.shuffle(x)
+        return np.resize(x, n)
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 166.0, -166.0, 166.3, -166.3, 600.0, -600.0, 700.0, -700.0, 709.0, -709.0, 709.78,
+                     -745.13, 1e-300, -1e-300, 5e-324, 0.5, 2.0, np.log(2.0), 1e-17, -1e-17])
+    k = max(n // 4, 1)
+    if fn == "exp":
+        return mix([rng.uniform(-745.2, 709.78, 2 * k), rng.uniform(-1, 1, k), rng.normal(0, 40, k), edge]), None
+    if fn == "log":
+        return mix([np.ldexp(rng.uniform(0.5, 1, 2 * k), rng.integers(-1073, 1024, 2 * k)), 1 + rng.normal(0, 1e-3, k),
+                    np.exp(rng.uniform(-170, 170, k)), np.abs(edge[edge != 0])]), None
+    if fn == "boxplus":
+        a = mix([rng.normal(0, 10, k), rng.uniform(-50, 50, k), rng.uniform(-700, 700, k), rng.normal(0, 0.01, k), edge])
+        b = mix([rng.normal(0, 10, k), rng.uniform(-50, 50, k), rng.uniform(-700, 700, k), a[:k] * rng.choice([-1, 1], k), edge[::-1]])
+        return a, b
+    if fn == "ratio_div":
+        a = np.ldexp(rng.uniform(0.5, 1, n), rng.integers(-499, 500, n))
+        q = np.ldexp(rng.uniform(0.5, 1, n), rng.integers(-499, 500, n))
+        b = a / q
+        ok = (b > 2.0**-999) & (b < 2.0**999)
+        b[~ok] = 1.0
+        return a, b
+    if fn in ("ratio_rho", "ratio_lambda"):
+        lim = 240 * np.log(2.0) * (1 - 1e-12)
+        a = np.exp(mix([rng.uniform(-lim, lim, 2 * k), rng.normal(0, 5, 2 * k), np.array([lim, -lim, 0.0])]))
+        b = np.exp(mix([rng.uniform(-lim, lim, 2 * k), rng.normal(0, 5, 2 * k), np.array([-lim, lim, 0.0])]))
+        return a, b
+    if fn == "e_combine":
+        return np.exp(-mix([rng.uniform(0, 600, 3 * k), rng.exponential(3, k), np.array([0.0, 600.0])])), \
+               np.exp(-mix([rng.uniform(0, 600, 3 * k), rng.exponential(3, k), np.array([600.0, 0.0])]))
+    if fn == "exp_clamped":
+        return mix([rng.uniform(-705, 705, 3 * k), rng.normal(0, 20, k), edge[np.abs(edge) <= 709]]), None
+    if fn == "boxplus_exp":
+        return mix([rng.uniform(0, 710, 2 * k), rng.exponential(5, 2 * k), np.abs(edge)]), None
+    if fn == "boxplus_log":
+        return mix([rng.uniform(0.5, 2, 3 * k), 1 + rng.normal(0, 1e-6, k), np.array([0.5, 1.0, 2.0])]), None
+    d = int(fn[-1])
+    if fn.startswith("cn_ratio"):
+        lim = 240 * np.log(2.0) * (1 - 1e-12)
+        L = np.concatenate([rng.uniform(-lim, lim, (n // 2, d)), rng.normal(0, 6, (n - n // 2 - 2, d)),
+                            np.full((1, d), lim), np.full((1, d), -lim)])
+        return np.exp(L), None
+    L = np.concatenate([rng.normal(0, 10, (n // 2, d)), rng.uniform(-100, 100, (n - n // 2 - 2, d)),
+                        np.full((1, d), 600.0), np.zeros((1, d))])
+    return L, None

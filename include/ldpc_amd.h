@@ -170,6 +170,42 @@ uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per
 int ldpc_hip_simulate(ldpc_hip_ctx *ctx, decoder_param dec, channel_param ch, simulation_param sim,
                       sim_results_t *results, uint64_t *totals, bool *stopFlag, int cli_output);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Part 3 — several GPUs, one process per GPU                                     */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference shares its counters between OpenMP threads (ldpcsim.cpp:175-252); here the ranks of a sharded
+   simulation exchange them, and the accepted-pair counts that place each rank in the one noise stream, through a
+   communicator: RCCL over xGMI (one rank per GPU), or a host shared-memory segment for rehearsals in which ranks
+   share a GPU and for tests without one.  All payloads are a few 64-bit words per rank. */
+typedef struct ldpc_hip_comm ldpc_hip_comm;
+
+/* rank 0 obtains an RCCL unique id (ncclGetUniqueId: 128 bytes) and hands the bytes to every rank by whatever means
+   the launcher has (torch.distributed in bench.py, pipes in `ldpcsim --devices`) */
+int ldpc_hip_comm_unique_id(uint8_t id[128]);
+/* RCCL communicator of `world` ranks; this rank uses GPU `device` (ncclCommInitRank: collective, blocks) */
+ldpc_hip_comm *ldpc_hip_comm_create(int rank, int world, int device, const uint8_t id[128]);
+/* host shared-memory communicator; `name` ("/something") is the same on every rank and unique to the job */
+ldpc_hip_comm *ldpc_hip_comm_create_shm(int rank, int world, const char *name);
+void ldpc_hip_comm_destroy(ldpc_hip_comm *comm);
+/* recv[q*bytes ..) = rank q's send[0 .. bytes): host buffers, bytes a multiple of 8 and at most 256 */
+int ldpc_hip_comm_allgather(ldpc_hip_comm *comm, const void *send, void *recv, uint64_t bytes);
+
+/* frames the output buffers of ldpc_hip_stream_decode_sharded must hold for a step of target_frames frames */
+uint64_t ldpc_hip_shard_capacity(uint64_t target_frames, int world);
+/* this rank's share of the next global step of about target_frames frames of the stream (all ranks call it with the same
+   arguments).  AWGN: the step is a range of the raw mt19937_64 stream cut into `world` pieces; each rank generates and
+   scans its own piece only, one all-gather of the accepted-pair counts tells every rank where its piece starts in the
+   pair sequence, and a frame belongs to the rank whose piece holds its first pair.  BSC / BEC: even split.
+   step[0..3] = first frame and frame count of the global step, first frame and frame count of this rank. */
+int ldpc_hip_stream_decode_sharded(ldpc_hip_ctx *ctx, ldpc_hip_comm *comm, decoder_param dec, uint64_t target_frames,
+                                   const ldpc_hip_out *out, uint64_t step[4], void *hip_stream);
+/* ldpc_hip_simulate over the ranks of `comm`: every rank returns the counters of the one-rank run with the same
+   arguments (the stop rule of ldpcsim.cpp:255 is applied in stream order across the ranks); rank 0 prints and writes
+   the result file */
+int ldpc_hip_simulate_sharded(ldpc_hip_ctx *ctx, ldpc_hip_comm *comm, decoder_param dec, channel_param ch,
+                              simulation_param sim, sim_results_t *results, uint64_t *totals, bool *stopFlag,
+                              int cli_output);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

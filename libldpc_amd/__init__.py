@@ -9,5 +9,5 @@ host runtime, see include/ldpc_amd.h).  This package is the thin host-side mirro
 
 There is no CPU fallback: without the built library, or without a GPU, calls fail loudly.
 """
-from .binding import LIB_PATH, HipDecoder, load_library  # noqa: F401
+from .binding import LIB_PATH, Comm, HipDecoder, load_library  # noqa: F401
 from .ldpc import LDPC  # noqa: F401

@@ -79,6 +79,22 @@ def load_library(path=LIB_PATH):
     L.ldpc_hip_set_profiling.argtypes = [vp, i32]
     L.ldpc_hip_last_ms.restype = ct.c_float
     L.ldpc_hip_last_ms.argtypes = [vp, i32]
+    L.ldpc_hip_comm_unique_id.restype = i32
+    L.ldpc_hip_comm_unique_id.argtypes = [vp]
+    L.ldpc_hip_comm_create.restype = vp
+    L.ldpc_hip_comm_create.argtypes = [i32, i32, i32, vp]
+    L.ldpc_hip_comm_create_shm.restype = vp
+    L.ldpc_hip_comm_create_shm.argtypes = [i32, i32, ct.c_char_p]
+    L.ldpc_hip_comm_destroy.argtypes = [vp]
+    L.ldpc_hip_comm_allgather.restype = i32
+    L.ldpc_hip_comm_allgather.argtypes = [vp, vp, vp, u64]
+    L.ldpc_hip_shard_capacity.restype = u64
+    L.ldpc_hip_shard_capacity.argtypes = [u64, i32]
+    L.ldpc_hip_stream_decode_sharded.restype = i32
+    L.ldpc_hip_stream_decode_sharded.argtypes = [vp, vp, decoder_param, u64, ct.POINTER(ldpc_hip_out), vp, vp]
+    L.ldpc_hip_simulate_sharded.restype = i32
+    L.ldpc_hip_simulate_sharded.argtypes = [vp, vp, decoder_param, channel_param, simulation_param, ct.POINTER(sim_results_t),
+                                            vp, ct.POINTER(ct.c_bool), i32]
     L.ldpc_hip_selftest_math.restype = i32
     L.ldpc_hip_selftest_math.argtypes = [vp, i32, u64, vp, vp, vp]
     L.ldpc_hip_selftest_chunk_table.restype = u64
@@ -106,6 +122,45 @@ def _ptr(buf):
 
 def _dec(early_term, iterations, decoding):
     return decoder_param(bool(early_term), int(iterations), decoding.encode())
+
+
+class Comm:
+    """The exchange between the ranks of a sharded simulation (include/ldpc_amd.h part 3): RCCL when `unique_id` (128
+    bytes from Comm.unique_id() on rank 0) is given, host shared memory when `shm_name` is."""
+
+    def __init__(self, rank, world, device=0, unique_id=None, shm_name=None, lib=LIB_PATH):
+        self.lib = load_library(lib)
+        self.rank, self.world = int(rank), int(world)
+        if shm_name is not None:
+            self.handle = self.lib.ldpc_hip_comm_create_shm(self.rank, self.world, shm_name.encode())
+        else:
+            buf = (ct.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+            self.handle = self.lib.ldpc_hip_comm_create(self.rank, self.world, int(device), buf)
+        if not self.handle:
+            raise RuntimeError("communicator: " + self.lib.ldpc_hip_last_error().decode())
+
+    @staticmethod
+    def unique_id(lib=LIB_PATH):
+        L = load_library(lib)
+        buf = (ct.c_uint8 * 128)()
+        if L.ldpc_hip_comm_unique_id(buf) != 0:
+            raise RuntimeError("ldpc_hip_comm_unique_id: " + L.ldpc_hip_last_error().decode())
+        return bytes(buf)
+
+    def all_gather(self, values):
+        """values: 1-D uint64 array (at most 32 words) -> [world][len] array"""
+        v = np.ascontiguousarray(values, np.uint64)
+        out = np.zeros((self.world, v.size), np.uint64)
+        if self.lib.ldpc_hip_comm_allgather(self.handle, v.ctypes.data, out.ctypes.data, v.nbytes) != 0:
+            raise RuntimeError("ldpc_hip_comm_allgather: " + self.lib.ldpc_hip_last_error().decode())
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ldpc_hip_comm_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
 
 
 class HipDecoder:
@@ -174,6 +229,22 @@ class HipDecoder:
                                                     ct.byref(s), stream), "ldpc_hip_stream_decode")
         return bufs
 
+    def shard_capacity(self, target_frames, world):
+        return int(self.lib.ldpc_hip_shard_capacity(int(target_frames), int(world)))
+
+    def stream_decode_sharded(self, comm, target_frames, early_term=True, iterations=50, decoding="BP",
+                              want=("iters", "bit_errors"), out=None, stream=None):
+        """This rank's share of the next global step of about target_frames frames (every rank calls it).  Returns
+        (buffers, step) with step = (step_first, step_frames, first, n); only the first n entries of the buffers are
+        this rank's frames."""
+        cap = self.shard_capacity(target_frames, comm.world)
+        s, bufs = self._outs(cap, want, out)
+        step = (ct.c_uint64 * 4)()
+        self._check(self.lib.ldpc_hip_stream_decode_sharded(self.ctx, comm.handle, _dec(early_term, iterations, decoding),
+                                                            int(target_frames), ct.byref(s), step, stream),
+                    "ldpc_hip_stream_decode_sharded")
+        return bufs, tuple(int(v) for v in step)
+
     @property
     def stream_frame(self):
         return self.lib.ldpc_hip_stream_frame(self.ctx)
@@ -223,7 +294,7 @@ class HipDecoder:
         return out
 
     def simulate(self, channel, x_range, seed=0, early_term=True, iterations=50, decoding="BP",
-                 max_frames=10**10, fec=50, result_file="", cli_output=False):
+                 max_frames=10**10, fec=50, result_file="", cli_output=False, comm=None):
         n_max = max(1, int(np.ceil((x_range[1] - x_range[0]) / x_range[2])) + 2)
         arrs = {k: np.zeros(n_max, np.float64) for k in ("fer", "ber", "avg_iter", "time")}
         arrs["fec"] = np.zeros(n_max, np.uint64)
@@ -235,8 +306,12 @@ class HipDecoder:
         stop = ct.c_bool(False)
         ch = channel_param(int(seed), (ct.c_double * 3)(*x_range), channel.encode())
         sp = simulation_param(1, int(max_frames), int(fec), result_file.encode())
-        nx = self.lib.ldpc_hip_simulate(self.ctx, _dec(early_term, iterations, decoding), ch, sp, ct.byref(res),
-                                        totals.ctypes.data, ct.byref(stop), int(cli_output))
+        if comm is not None:
+            nx = self.lib.ldpc_hip_simulate_sharded(self.ctx, comm.handle, _dec(early_term, iterations, decoding), ch, sp,
+                                                    ct.byref(res), totals.ctypes.data, ct.byref(stop), int(cli_output))
+        else:
+            nx = self.lib.ldpc_hip_simulate(self.ctx, _dec(early_term, iterations, decoding), ch, sp, ct.byref(res),
+                                            totals.ctypes.data, ct.byref(stop), int(cli_output))
         if nx < 0:
             raise RuntimeError("ldpc_hip_simulate: " + self.lib.ldpc_hip_last_error().decode())
         out = {k: v[:nx] for k, v in arrs.items()}

@@ -20,6 +20,11 @@
 
 using namespace ldpc_amd;
 
+struct ldpc_hip_comm
+{
+    std::unique_ptr<Comm> comm;
+};
+
 struct ldpc_hip_ctx
 {
     std::unique_ptr<Engine> eng;
@@ -403,6 +408,76 @@ uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per
         return ~0ull;
     }
     return max_row;
+}
+
+int ldpc_hip_comm_unique_id(uint8_t id[128])
+{
+    return guarded([&] { rccl_unique_id(id); });
+}
+
+ldpc_hip_comm *ldpc_hip_comm_create(int rank, int world, int device, const uint8_t id[128])
+{
+    ldpc_hip_comm *c = nullptr;
+    if (guarded([&] {
+            auto p = std::make_unique<ldpc_hip_comm>();
+            p->comm = make_rccl_comm(rank, world, device, id);
+            c = p.release();
+        }) != 0)
+        return nullptr;
+    return c;
+}
+
+ldpc_hip_comm *ldpc_hip_comm_create_shm(int rank, int world, const char *name)
+{
+    ldpc_hip_comm *c = nullptr;
+    if (guarded([&] {
+            auto p = std::make_unique<ldpc_hip_comm>();
+            p->comm = make_shm_comm(rank, world, name ? name : "/ldpc_amd");
+            c = p.release();
+        }) != 0)
+        return nullptr;
+    return c;
+}
+
+void ldpc_hip_comm_destroy(ldpc_hip_comm *comm) { delete comm; }
+
+int ldpc_hip_comm_allgather(ldpc_hip_comm *comm, const void *send, void *recv, uint64_t bytes)
+{
+    return guarded([&] { comm->comm->all_gather(send, recv, bytes); });
+}
+
+uint64_t ldpc_hip_shard_capacity(uint64_t target_frames, int world) { return Engine::shard_capacity(target_frames, world < 1 ? 1 : world); }
+
+int ldpc_hip_stream_decode_sharded(ldpc_hip_ctx *ctx, ldpc_hip_comm *comm, decoder_param dec, uint64_t target_frames,
+                                   const ldpc_hip_out *out, uint64_t step[4], void *hip_stream)
+{
+    return guarded([&] {
+        const Engine::ShardStep st = ctx->eng->stream_decode_sharded(*comm->comm, to_params(dec), target_frames, to_out(out), hip_stream);
+        if (step)
+            step[0] = st.step_first, step[1] = st.step_frames, step[2] = st.first, step[3] = st.n;
+    });
+}
+
+int ldpc_hip_simulate_sharded(ldpc_hip_ctx *ctx, ldpc_hip_comm *comm, decoder_param dec, channel_param ch,
+                              simulation_param sim, sim_results_t *results, uint64_t *totals, bool *stopFlag, int cli_output)
+{
+    int n = -1;
+    int rc = guarded([&] {
+        SimRequest rq;
+        rq.dec = to_params(dec);
+        rq.channel = channel_from(ch.type);
+        if (!rq.channel)
+            throw std::runtime_error("No channel selected.");
+        rq.seed = ch.seed;
+        for (int i = 0; i < 3; ++i)
+            rq.x_range[i] = ch.xRange[i];
+        rq.max_frames = sim.maxFrames;
+        rq.min_fec = sim.fec;
+        rq.result_file = sim.resultFile ? sim.resultFile : "";
+        rq.cli_output = cli_output != 0;
+        n = run_simulation(*ctx->eng, rq, results, totals, stopFlag, comm ? comm->comm.get() : nullptr);
+    });
+    return rc == 0 ? n : -1;
 }
 
 int ldpc_hip_simulate(ldpc_hip_ctx *ctx, decoder_param dec, channel_param ch, simulation_param sim,

@@ -1,0 +1,50 @@
+// comm.hpp — the one exchange step of the multi-GPU path: small all-gathers between the ranks of a
+// sharded simulation (one process per GPU).  Two transports behind one interface:
+//
+//   RcclComm  RCCL (ncclAllGather over xGMI) on device buffers, librccl.so loaded on first use.  The communicator is
+//             built from an ncclUniqueId the launcher distributes (torch.distributed in bench.py, pipes in
+//             `ldpcsim --devices`), exactly like ncclCommInitRank.
+//   ShmComm   a POSIX shared-memory segment on the host: rehearsals in which several ranks share one GPU (RCCL
+//             refuses two ranks on one device) and tests without a GPU.
+//
+// The reference has no communication at all (OpenMP threads share counters, ldpcsim.cpp:175-252); what crosses
+// ranks here is what those shared counters carried, plus the accepted-pair counts that place every rank in the
+// one noise stream.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace ldpc_amd
+{
+
+constexpr size_t kCommIdBytes = 128; // NCCL_UNIQUE_ID_BYTES
+
+class Comm
+{
+  public:
+    virtual ~Comm() = default;
+    int rank() const { return rank_; }
+    int world() const { return world_; }
+    // recv[q*bytes .. (q+1)*bytes) = rank q's send[0..bytes), host buffers, blocking; bytes <= kMaxBytes
+    virtual void all_gather(const void *send, void *recv, size_t bytes) = 0;
+    virtual const char *transport() const = 0;
+    static constexpr size_t kMaxBytes = 256;
+
+    // sum of n int64 values over all ranks (an all-gather and a local sum: the payloads are a few words)
+    void all_reduce_sum(int64_t *values, size_t n);
+
+  protected:
+    int rank_ = 0, world_ = 1;
+};
+
+// fills id[kCommIdBytes] with a fresh ncclUniqueId (rank 0 calls this, every rank gets the bytes)
+void rccl_unique_id(uint8_t *id);
+std::unique_ptr<Comm> make_rccl_comm(int rank, int world, int device, const uint8_t *id);
+// name: shared-memory object name, the same on every rank and unique to the job (e.g. "/ldpc_amd_<port>")
+std::unique_ptr<Comm> make_shm_comm(int rank, int world, const std::string &name);
+
+} // namespace ldpc_amd

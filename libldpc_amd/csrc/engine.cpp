@@ -727,6 +727,7 @@ void Engine::stream_begin(int channel, uint64_t seed, double x, bool fresh)
     frame_pos_ = 0;
     pair_next_ = 0;
     raw_next_ = 0;
+    stream_mode_ = 0;
     noise_.reset(seed);
     if (fresh || info_.seed() != (seed << 1))
     {
@@ -745,24 +746,28 @@ void Engine::stream_begin(int channel, uint64_t seed, double x, bool fresh)
 
 uint64_t Engine::stream_raw_draws() const { return raw_next_; }
 
+void Engine::ensure_rng_stream()
+{
+    if (rng_stream_)
+        return;
+    // non-blocking: no implicit ordering with the caller's (possibly default) stream
+    hipStream_t rs;
+    check(hipStreamCreateWithFlags(&rs, hipStreamNonBlocking), "hipStreamCreate");
+    rng_stream_ = rs;
+    for (int i = 0; i < 2; ++i)
+    {
+        hipEvent_t e0, e1;
+        check(hipEventCreateWithFlags(&e0, hipEventDisableTiming), "hipEventCreate");
+        check(hipEventCreateWithFlags(&e1, hipEventDisableTiming), "hipEventCreate");
+        ev_pairs_ready_[i] = e0, ev_pairs_free_[i] = e1;
+    }
+}
+
 // Locate the accepted polar pairs that supply the normals of frames [frame_pos_, frame_pos_+n).
 void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream)
 {
     hipStream_t user = static_cast<hipStream_t>(stream);
-    if (!rng_stream_)
-    {
-        // non-blocking: no implicit ordering with the caller's (possibly default) stream
-        hipStream_t rs;
-        check(hipStreamCreateWithFlags(&rs, hipStreamNonBlocking), "hipStreamCreate");
-        rng_stream_ = rs;
-        for (int i = 0; i < 2; ++i)
-        {
-            hipEvent_t e0, e1;
-            check(hipEventCreateWithFlags(&e0, hipEventDisableTiming), "hipEventCreate");
-            check(hipEventCreateWithFlags(&e1, hipEventDisableTiming), "hipEventCreate");
-            ev_pairs_ready_[i] = e0, ev_pairs_free_[i] = e1;
-        }
-    }
+    ensure_rng_stream();
     hipStream_t s = static_cast<hipStream_t>(rng_stream_);
     const int buf = pp_;
     pp_ ^= 1;
@@ -840,6 +845,9 @@ void Engine::stream_decode(const DecParams &p, uint64_t n_frames, const BatchOut
         throw std::runtime_error("stream_begin() has not been called");
     if (n_frames == 0)
         return;
+    if (stream_mode_ == 2)
+        throw std::runtime_error("stream_decode after stream_decode_sharded on the same stream: call stream_begin first");
+    stream_mode_ = 1;
     upload_plan();
     const uint64_t nct = static_cast<uint64_t>(plan_.nct), nc = static_cast<uint64_t>(plan_.nc);
     const uint64_t sub = max_sub_batch();
@@ -883,6 +891,186 @@ void Engine::stream_decode(const DecParams &p, uint64_t n_frames, const BatchOut
         frame_pos_ += n;
         done += n;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+uint64_t Engine::shard_capacity(uint64_t target_frames, int world)
+{
+    const uint64_t per = (target_frames + world - 1) / world;
+    return per + per / 16 + 64; // the acceptance count of a piece varies by a few parts in a thousand
+}
+
+void Engine::encoder_snapshot(void *stream)
+{
+    if (!code_->has_G())
+        return;
+    bind_device();
+    const size_t nc = plan_.nc;
+    enc_snap_pos_ = info_pos_;
+    enc_snap_valid_ = cw_run_valid_;
+    if (cw_run_valid_)
+        check(hipMemcpyAsync(enc_snap_.reserve(nc), cw_run_.get(), nc, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)),
+              "encoder snapshot");
+}
+
+void Engine::encoder_restore_and_skip(uint64_t frames, void *stream)
+{
+    if (!code_->has_G())
+        return;
+    bind_device();
+    const size_t nc = plan_.nc;
+    info_pos_ = enc_snap_pos_;
+    cw_run_valid_ = enc_snap_valid_;
+    if (enc_snap_valid_)
+        check(hipMemcpyAsync(cw_run_.reserve(nc), enc_snap_.get(), nc, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)),
+              "encoder restore");
+    for (uint64_t left = frames; left;)
+    {
+        const uint64_t n = std::min<uint64_t>(left, 1u << 17);
+        encode_frames(n, false, stream);
+        left -= n;
+    }
+    last_enc_n_ = 0;
+}
+
+Engine::ShardStep Engine::stream_decode_sharded(Comm &comm, const DecParams &p, uint64_t target_frames, const BatchOut &out,
+                                                void *stream)
+{
+    if (!chan_)
+        throw std::runtime_error("stream_begin() has not been called");
+    upload_plan();
+    const int R = comm.world(), r = comm.rank();
+    const uint64_t nct = static_cast<uint64_t>(plan_.nct), cap = shard_capacity(target_frames, R);
+    if (cap > max_sub_batch())
+        throw std::runtime_error("sharded step too large for one launch per rank");
+    target_frames = std::max<uint64_t>(target_frames, 1);
+    if (stream_mode_ == 1)
+        throw std::runtime_error("stream_decode_sharded after stream_decode on the same stream: call stream_begin first");
+    stream_mode_ = 2;
+    ShardStep st;
+    st.step_first = frame_pos_;
+    DecodeArgs a{};
+    if (chan_ == kAwgn)
+    {
+        ensure_rng_stream();
+        hipStream_t s = static_cast<hipStream_t>(rng_stream_), user = static_cast<hipStream_t>(stream);
+        const int buf = pp_;
+        pp_ ^= 1;
+        if (pairs_in_use_[buf])
+            check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev_pairs_free_[buf]), 0), "wait pairs free");
+        // the step: T trials of the raw stream, a multiple of R scan blocks, enough for about target_frames frames
+        const uint64_t want_pairs = (target_frames * nct + 1) / 2;
+        const uint64_t unit = static_cast<uint64_t>(R) * kScanBlock;
+        const uint64_t T = std::max<uint64_t>(unit, static_cast<uint64_t>(static_cast<double>(want_pairs) * 1.2732395447351628) / unit * unit);
+        const uint64_t piece = T / R;
+        // margin: the pairs of one frame beyond the piece (the last frame a rank owns may end in its neighbour's piece)
+        const uint64_t margin = ((nct / 2 + 2) * 2 + 4 * kScanBlock - 1) / kScanBlock * kScanBlock;
+        const uint64_t t0 = raw_next_ / 2 + static_cast<uint64_t>(r) * piece;
+        prof_mark(1, s);
+        const uint64_t *raw = noise_.generate(2 * t0, 2 * (piece + margin), s);
+        const uint32_t n_blocks = static_cast<uint32_t>((piece + margin) / kScanBlock);
+        uint32_t *counts = static_cast<uint32_t *>(scan_counts_.reserve(4 * static_cast<size_t>(n_blocks)));
+        uint64_t *offs = static_cast<uint64_t *>(scan_offsets_.reserve(8 * static_cast<size_t>(n_blocks)));
+        ScanResult *res = static_cast<ScanResult *>(scan_result_.reserve(2 * sizeof(ScanResult)));
+        check(launch_polar_count(raw, piece + margin, piece, counts, offs, res, res + 1, s), "polar_count");
+        ScanResult h[2];
+        check(hipMemcpyAsync(h, res, sizeof h, hipMemcpyDeviceToHost, s), "scan result");
+        check(hipStreamSynchronize(s), "sync");
+        // the exchange: every rank's accepted-pair count of its piece -> where each piece starts in the pair sequence
+        std::vector<uint64_t> acc(R);
+        const uint64_t mine = h[0].accepted;
+        comm.all_gather(&mine, acc.data(), sizeof mine);
+        std::vector<uint64_t> P(R + 1);
+        P[0] = pair_next_;
+        for (int q = 0; q < R; ++q)
+            P[q + 1] = P[q] + acc[q];
+        auto first_frame = [&](uint64_t pair) { return (2 * pair + nct - 1) / nct; }; // first frame whose first pair is >= pair
+        st.first = first_frame(P[r]);
+        st.n = first_frame(P[r + 1]) - st.first;
+        st.step_frames = first_frame(P[R]) - st.step_first;
+        if (first_frame(P[0]) != frame_pos_)
+            throw std::runtime_error("sharded stream out of step");
+        if (st.n > cap)
+            throw std::runtime_error("sharded step: more frames in a piece than the output buffers hold");
+        if (st.n)
+        {
+            const uint64_t last_pair = ((st.first + st.n) * nct - 1) >> 1;
+            const uint64_t need = last_pair - P[r] + 1;
+            if (need > h[1].accepted)
+                throw std::runtime_error("sharded step: a frame extends beyond the margin scanned after the piece");
+            uint64_t *pairs = static_cast<uint64_t *>(pairs_[buf].reserve(16 * (need + 1)));
+            check(launch_polar_compact(raw, piece + margin, offs, need, pairs, res, s), "polar_compact");
+            a.pairs = pairs;
+            a.pair_base = P[r];
+        }
+        prof_mark(1, s);
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_ready_[buf]), s), "event");
+        check(hipStreamWaitEvent(user, static_cast<hipEvent_t>(ev_pairs_ready_[buf]), 0), "wait pairs ready");
+        a.mode = kModeAwgn;
+        a.normal_base = st.first * nct;
+        a.sigma = sigma_, a.sigma2 = sigma2_;
+        a.shorten_llr = 99999.9; // channel.cpp:83
+        a.pairs_buffer = buf;
+        pair_next_ = P[R];
+        raw_next_ += 2 * T;
+    }
+    else
+    {
+        st.step_frames = target_frames;
+        const uint64_t base = target_frames / R, extra = target_frames % R;
+        st.n = base + (static_cast<uint64_t>(r) < extra ? 1 : 0);
+        st.first = st.step_first + base * r + std::min<uint64_t>(r, extra);
+    }
+    // encoder: every rank walks the whole step's info words (kc draws per frame, a tenth of the noise stream's) so
+    // that all of them hold the same accumulated codeword afterwards; codewords are formed for the own frames only
+    const uint8_t *cw = nullptr;
+    if (code_->has_G())
+    {
+        for (uint64_t left = st.first - st.step_first; left;)
+        {
+            const uint64_t n = std::min<uint64_t>(left, 1u << 17);
+            encode_frames(n, false, stream);
+            left -= n;
+        }
+        cw = encode_frames(st.n, true, stream);
+        for (uint64_t left = st.step_first + st.step_frames - (st.first + st.n); left;)
+        {
+            const uint64_t n = std::min<uint64_t>(left, 1u << 17);
+            encode_frames(n, false, stream);
+            left -= n;
+        }
+        last_enc_n_ = 0;
+    }
+    if (st.n)
+    {
+        if (chan_ == kAwgn)
+        {
+            a.codeword = cw;
+            run_decode(a, p, out, st.n, stream);
+        }
+        else if (chan_ == kBsc)
+        {
+            a.mode = kModeBsc;
+            a.codeword = cw;
+            a.raw = noise_.generate(st.first * nct, st.n * nct, stream);
+            a.eps = x_, a.delta = delta_;
+            a.shorten_llr = delta_; // channel.cpp:152
+            run_decode(a, p, out, st.n, stream);
+        }
+        else
+        {
+            const uint64_t keep_raw = raw_next_;
+            raw_next_ = st.first * nct; // run_bec reads the stream at raw_next_
+            run_bec(p, out, st.n, cw, stream);
+            raw_next_ = keep_raw;
+        }
+    }
+    else if (chan_ == kAwgn && a.pairs_buffer >= 0)
+        pairs_in_use_[a.pairs_buffer] = false;
+    if (chan_ != kAwgn)
+        raw_next_ = (st.step_first + st.step_frames) * nct;
+    frame_pos_ = st.step_first + st.step_frames;
+    return st;
 }
 
 } // namespace ldpc_amd

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "code.hpp"
+#include "comm.hpp"
 #include "kernels.hpp"
 #include "mt64.hpp"
 #include "plan.hpp"
@@ -144,6 +145,24 @@ class Engine
     // (info-word stream position and accumulated codeword), so that the next channel point continues where a
     // frame-by-frame run that stopped inside the batch would (the noise stream restarts per point anyway).
     void stream_rewind_encoder(uint64_t frames_back, void *stream);
+    // ---- the same stream decoded by several ranks (one process per GPU), SURVEY §8e ----
+    // One global step of about target_frames frames.  AWGN: the step is a fixed range of the RAW stream cut into
+    // world equal pieces; rank r generates and scans only its piece (+ a margin of one frame's worth), the ranks
+    // all-gather their accepted-pair counts (one u64 each), and a frame belongs to the rank whose piece holds its
+    // first pair — so every frame keeps its place in mt19937_64(seed) and nobody scans another rank's noise.
+    // BSC / BEC draw once per bit: frames split evenly, no exchange.  Every rank ends the step with the same
+    // stream position.  `out` must hold shard_capacity(target_frames, world) frames.
+    struct ShardStep
+    {
+        uint64_t step_first = 0, step_frames = 0; // the global step
+        uint64_t first = 0, n = 0;                // this rank's frames [first, first + n)
+    };
+    static uint64_t shard_capacity(uint64_t target_frames, int world);
+    ShardStep stream_decode_sharded(Comm &comm, const DecParams &p, uint64_t target_frames, const BatchOut &out, void *stream);
+    // encoder state (info-word stream position + accumulated codeword) saved before a step / put back and advanced by
+    // `frames` frames: how every rank lands on the state after the frame at which the simulation stopped
+    void encoder_snapshot(void *stream);
+    void encoder_restore_and_skip(uint64_t frames, void *stream);
     uint64_t stream_frame() const { return frame_pos_; }
     uint64_t stream_raw_draws() const;
 
@@ -157,6 +176,7 @@ class Engine
 
   private:
     void bind_device();
+    void ensure_rng_stream();
     void upload_plan();
     void run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, uint64_t n, void *stream);
     void run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const uint8_t *codeword, void *stream);
@@ -180,6 +200,7 @@ class Engine
     int chan_ = 0;
     double x_ = 0, sigma2_ = 0, sigma_ = 0, delta_ = 0;
     uint64_t frame_pos_ = 0;
+    int stream_mode_ = 0; // 0 fresh, 1 stream_decode / stream_skip, 2 stream_decode_sharded (pair bookkeeping differs)
     uint64_t pair_next_ = 0; // accepted polar pairs located so far
     uint64_t raw_next_ = 0;  // raw draws consumed so far (AWGN: where the next trial starts)
     MtStream noise_, info_;
@@ -197,6 +218,9 @@ class Engine
     int pp_ = 0;
     DeviceBuffer stage_in_, stage_iters_, stage_be_, stage_hard_, stage_llr_out_, stage_llr_in_, stage_cw_;
     DeviceBuffer ws_msg_, ws_llr_, ws_hb_;
+    DeviceBuffer enc_snap_;
+    uint64_t enc_snap_pos_ = 0;
+    bool enc_snap_valid_ = false;
     DeviceBuffer redo_; // [0] = count, [1..] = frames handed back by the ratio-form launch
     bool profiling_ = false;
     std::vector<void *> prof_pending_[2], prof_free_; // hipEvent_t: begin/end pairs per launch, spare events

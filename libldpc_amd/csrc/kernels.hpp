@@ -164,6 +164,14 @@ struct ScanResult
 constexpr uint32_t kScanBlock = 2048;
 int launch_polar_scan(const uint64_t *raw, uint64_t n_trials, uint64_t want_pairs, uint32_t *block_counts,
                       uint64_t *block_offsets, uint64_t *pairs_out, ScanResult *result, void *stream);
+// the same in two halves, for a rank that owns a PIECE of the raw stream (sharded simulation): count the accepted
+// trials of n_trials = piece + margin trials per block and report how many lie in the first piece_trials
+// (result->accepted; a multiple of kScanBlock) and in all of them (result_all->accepted); then, once the ranks have
+// exchanged their counts, compact the first want_pairs accepted pairs
+int launch_polar_count(const uint64_t *raw, uint64_t n_trials, uint64_t piece_trials, uint32_t *block_counts,
+                       uint64_t *block_offsets, ScanResult *result, ScanResult *result_all, void *stream);
+int launch_polar_compact(const uint64_t *raw, uint64_t n_trials, const uint64_t *block_offsets, uint64_t want_pairs,
+                         uint64_t *pairs_out, ScanResult *result, void *stream);
 
 // GF(2) encoding on the reference's info-word stream (channel.cpp:44-60, sparse.h:163-172).
 // The reference draws kc bernoulli(0.5) bits per frame from mt19937_64(seed << 1) and ACCUMULATES u*G

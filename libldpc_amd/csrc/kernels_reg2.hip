@@ -92,7 +92,7 @@ __device__ __forceinline__ int wave_sum_i2(int v)
 template <typename T>
 __device__ __forceinline__ T __attribute__((address_space(3))) *lds_abs(uint32_t byte_address)
 {
-    return (T __attribute__((address_space(3))) *)(byte_address);
+    return (T __attribute__((address_space(3))) *)(static_cast<uintptr_t>(byte_address));
 }
 
 __device__ __forceinline__ Reg2VnBlock load_vn_block(const Reg2VnBlock *table, uint32_t i) // {u32, u32, u32, u16, u16}

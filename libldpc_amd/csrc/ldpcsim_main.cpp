@@ -5,9 +5,17 @@
 //
 // Same positional arguments, flags, defaults, console table and result file; the frames are decoded on
 // the GPU in batches of the reference's single noise stream (seed as given; -t is accepted and ignored:
-// the batch replaces the OpenMP threads).  Extra flag: --device N (GPU index), --bec-compat (reproduce the
+// the batch replaces the OpenMP threads).  Extra flags: --device N (GPU index); --devices LIST (e.g. 0-7 or 0,2,4:
+// one process per listed GPU, forked before anything touches a GPU, the frames of every step shared out over them and
+// the counters exchanged over RCCL — results are those of the one-GPU run; --comm shm puts the exchange on host
+// shared memory instead, for rehearsals with a repeated device such as --devices 0,0); --bec-compat (reproduce the
 // reference's out-of-bounds read for erased degree-1 variable nodes).
+#include <fcntl.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -37,7 +45,32 @@ const char *kUsage =
     "--frame-error-count \tMaximum frame errors for given simulation point.\n"
     "--no-early-term     \tDisable early termination for decoding.\n"
     "--device            \tGPU index. (Default: 0)\n"
+    "--devices           \tGPUs to share the frames over, one process each: \"0-7\", \"0,1,2\".\n"
+    "--comm              \tExchange between those processes: \"rccl\" (default) or \"shm\".\n"
     "--bec-compat        \tBEC: erased degree-1 variable nodes emit 0 as the reference build does.\n";
+
+std::vector<int> parse_devices(const std::string &spec)
+{
+    std::vector<int> out;
+    size_t i = 0;
+    while (i < spec.size())
+    {
+        size_t j = spec.find(',', i);
+        const std::string part = spec.substr(i, j == std::string::npos ? std::string::npos : j - i);
+        const size_t dash = part.find('-');
+        if (dash == std::string::npos)
+            out.push_back(std::stoi(part));
+        else
+            for (int d = std::stoi(part.substr(0, dash)); d <= std::stoi(part.substr(dash + 1)); ++d)
+                out.push_back(d);
+        if (j == std::string::npos)
+            break;
+        i = j + 1;
+    }
+    if (out.empty() || out.size() > 64)
+        throw std::runtime_error("--devices: expected a list such as 0-7 or 0,1,2");
+    return out;
+}
 
 [[noreturn]] void fail(const std::string &msg)
 {
@@ -54,6 +87,8 @@ int main(int argc, char *argv[])
     unsigned long seed = 0, max_frames = static_cast<unsigned long>(10e9), fec = 50;
     bool no_early = false, bec_compat = false;
     int device = 0;
+    std::vector<int> devices;
+    std::string comm_kind = "rccl";
     try
     {
         for (int i = 1; i < argc; ++i)
@@ -89,6 +124,10 @@ int main(int argc, char *argv[])
                 no_early = true;
             else if (a == "--device")
                 device = std::stoi(value());
+            else if (a == "--devices")
+                devices = parse_devices(value());
+            else if (a == "--comm")
+                comm_kind = value();
             else if (a == "--bec-compat")
                 bec_compat = true;
             else if (a.size() > 1 && a[0] == '-' && !(std::isdigit(static_cast<unsigned char>(a[1])) || a[1] == '.'))
@@ -98,6 +137,8 @@ int main(int argc, char *argv[])
         }
         if (pos.size() != 5)
             throw std::runtime_error("expected: codefile output-file MIN MAX STEP");
+        if (comm_kind != "rccl" && comm_kind != "shm")
+            throw std::runtime_error("--comm: rccl or shm");
     }
     catch (const std::exception &e)
     {
@@ -115,6 +156,54 @@ int main(int argc, char *argv[])
     }
     if (range[0] > range[1])
         fail("snr min > snr max"); // sim_cpu.cpp:29
+
+    // ---- several GPUs: one process per device, forked before this process makes any HIP call ----
+    const int world = devices.empty() ? 1 : static_cast<int>(devices.size());
+    int rank = 0;
+    std::vector<pid_t> children;
+    std::vector<int> id_pipe_w; // parent -> child r: the RCCL unique id
+    int id_pipe_r = -1;
+    const std::string shm_name = "/ldpc_amd_" + std::to_string(static_cast<long>(getpid()));
+    if (world > 1)
+    {
+        std::fflush(stdout);
+        for (int r = 1; r < world; ++r)
+        {
+            int fds[2];
+            if (pipe(fds) != 0)
+                fail("pipe() failed");
+            const pid_t pid = fork();
+            if (pid < 0)
+                fail("fork() failed");
+            if (pid == 0)
+            {
+                rank = r;
+                close(fds[1]);
+                id_pipe_r = fds[0];
+                for (int w : id_pipe_w)
+                    close(w);
+                id_pipe_w.clear();
+                children.clear();
+                const int devnull = open("/dev/null", O_WRONLY); // rank 0 alone prints the banner, table and result file
+                if (devnull >= 0)
+                    dup2(devnull, STDOUT_FILENO);
+                break;
+            }
+            close(fds[0]);
+            id_pipe_w.push_back(fds[1]);
+            children.push_back(pid);
+        }
+        device = devices[rank];
+    }
+    auto reap = [&](int rc) {
+        for (pid_t c : children)
+        {
+            int st = 0;
+            if (waitpid(c, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
+                rc = rc ? rc : EXIT_FAILURE;
+        }
+        return rc;
+    };
 
     ldpc_hip_ctx *ctx = ldpc_hip_create(pos[0].c_str(), gen.c_str(), device);
     if (!ctx)
@@ -146,13 +235,51 @@ int main(int argc, char *argv[])
     channel_param cp{seed, {range[0], range[1], range[2]}, channel.c_str()};
     simulation_param sp{threads, max_frames, fec, pos[1].c_str()};
     bool stop = false;
-    int rc = ldpc_hip_simulate(ctx, dp, cp, sp, nullptr, nullptr, &stop, /*cli_output=*/1);
+    ldpc_hip_comm *comm = nullptr;
+    if (world > 1)
+    {
+        if (comm_kind == "rccl")
+        {
+            uint8_t id[128] = {0};
+            bool ok = true;
+            if (rank == 0)
+            {
+                ok = ldpc_hip_comm_unique_id(id) == 0;
+                for (int w : id_pipe_w)
+                {
+                    ok = ok && write(w, id, sizeof id) == static_cast<ssize_t>(sizeof id);
+                    close(w);
+                }
+            }
+            else
+                ok = read(id_pipe_r, id, sizeof id) == static_cast<ssize_t>(sizeof id);
+            if (ok)
+                comm = ldpc_hip_comm_create(rank, world, device, id);
+        }
+        else
+        {
+            for (int w : id_pipe_w)
+                close(w);
+            comm = ldpc_hip_comm_create_shm(rank, world, shm_name.c_str());
+        }
+        if (!comm)
+        {
+            std::fprintf(stderr, "Error: rank %d: communicator: %s\n", rank, ldpc_hip_last_error());
+            ldpc_hip_destroy(ctx);
+            return reap(EXIT_FAILURE);
+        }
+    }
+    int rc = comm ? ldpc_hip_simulate_sharded(ctx, comm, dp, cp, sp, nullptr, nullptr, &stop, /*cli_output=*/1)
+                  : ldpc_hip_simulate(ctx, dp, cp, sp, nullptr, nullptr, &stop, /*cli_output=*/1);
     if (rc < 0)
     {
         std::cout << "Error: ldpc_sim::ldpc_sim() " << ldpc_hip_last_error() << std::endl;
+        std::fprintf(stderr, "Error: rank %d: %s\n", rank, ldpc_hip_last_error());
         ldpc_hip_destroy(ctx);
-        return EXIT_FAILURE;
+        return reap(EXIT_FAILURE);
     }
+    if (comm)
+        ldpc_hip_comm_destroy(comm);
     ldpc_hip_destroy(ctx);
-    return 0;
+    return reap(0);
 }

@@ -346,4 +346,30 @@ int launch_polar_scan(const uint64_t *raw, uint64_t n_trials, uint64_t want_pair
     return hipGetLastError();
 }
 
+int launch_polar_count(const uint64_t *raw, uint64_t n_trials, uint64_t piece_trials, uint32_t *block_counts,
+                       uint64_t *block_offsets, ScanResult *result, ScanResult *result_all, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t n_blocks = static_cast<uint32_t>((n_trials + kScanBlock - 1) / kScanBlock);
+    if (n_blocks == 0 || piece_trials % kScanBlock != 0 || piece_trials > n_trials)
+        return hipErrorInvalidValue;
+    const uint32_t piece_blocks = static_cast<uint32_t>(piece_trials / kScanBlock);
+    hipLaunchKernelGGL(polar_count_kernel, dim3(n_blocks), dim3(kScanThreads), 0, s, raw, n_trials, block_counts);
+    // offsets of the piece's blocks (gives the piece's total), then of all blocks (the ones the compaction uses)
+    hipLaunchKernelGGL(polar_offsets_kernel, dim3(1), dim3(1024), 0, s, block_counts, piece_blocks, block_offsets, 0ull, result);
+    hipLaunchKernelGGL(polar_offsets_kernel, dim3(1), dim3(1024), 0, s, block_counts, n_blocks, block_offsets, 0ull, result_all);
+    return hipGetLastError();
+}
+
+int launch_polar_compact(const uint64_t *raw, uint64_t n_trials, const uint64_t *block_offsets, uint64_t want_pairs,
+                         uint64_t *pairs_out, ScanResult *result, void *stream)
+{
+    const uint32_t n_blocks = static_cast<uint32_t>((n_trials + kScanBlock - 1) / kScanBlock);
+    if (n_blocks == 0)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(polar_compact_kernel, dim3(n_blocks), dim3(kScanThreads), 0, static_cast<hipStream_t>(stream), raw, n_trials,
+                       block_offsets, want_pairs, pairs_out, result);
+    return hipGetLastError();
+}
+
 } // namespace ldpc_amd

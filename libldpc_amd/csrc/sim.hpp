@@ -24,7 +24,10 @@ struct SimRequest
     uint64_t max_batch = 65536;
 };
 
-// returns the number of channel points
-int run_simulation(Engine &eng, const SimRequest &rq, sim_results_t *results, uint64_t *totals, bool *stop_flag);
+// returns the number of channel points.  comm != nullptr with more than one rank: the frames of every step are shared
+// out over the ranks (Engine::stream_decode_sharded) and the reference's counters and stop rule (ldpcsim.cpp:175-255)
+// are reduced in rank order, so that every rank returns the counters of a one-rank run; rank 0 prints and writes.
+int run_simulation(Engine &eng, const SimRequest &rq, sim_results_t *results, uint64_t *totals, bool *stop_flag,
+                   Comm *comm = nullptr);
 
 } // namespace ldpc_amd

@@ -1,0 +1,112 @@
+"""Several ranks on one stream (include/ldpc_amd.h part 3).  CPU: the host shared-memory communicator between real
+processes.  GPU: two ranks sharing cuda:0 decode disjoint parts of the same noise stream — every frame keeps the result
+it has in a one-rank run, and the sharded simulation returns the one-rank counters and result-file lines."""
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gather_worker(rank, world, name, q):
+    sys.path.insert(0, ROOT)
+    import libldpc_amd
+    c = libldpc_amd.Comm(rank, world, shm_name=name)
+    res = []
+    for k in range(50):  # alternating payload sizes, back to back: the two-slot reuse rule is exercised
+        v = np.arange(1 + k % 4, dtype=np.uint64) + 1000 * rank + k
+        res.append(c.all_gather(v))
+    q.put((rank, res))
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_shm_communicator_all_gather(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"/ldpc_amd_test_{os.getpid()}_{world}"
+    ps = [ctx.Process(target=_gather_worker, args=(r, world, name, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = dict(q.get(timeout=120) for _ in range(world))
+    [p.join(timeout=60) for p in ps]
+    for k in range(50):
+        want = np.stack([np.arange(1 + k % 4, dtype=np.uint64) + 1000 * r + k for r in range(world)])
+        for r in range(world):
+            assert np.array_equal(got[r][k], want), (k, r)
+
+
+def _shard_worker(rank, world, name, case, q):
+    sys.path.insert(0, ROOT)
+    import libldpc_amd
+    chan, x, seed, target, steps, decoding, gen = case
+    dec = libldpc_amd.HipDecoder(orc.H_TXT, orc.G_TXT if gen else "")
+    dec.set_bec_compat(True)
+    comm = libldpc_amd.Comm(rank, world, shm_name=name)
+    dec.stream_begin(chan, seed, x)
+    out = []
+    for _ in range(steps):
+        bufs, step = dec.stream_decode_sharded(comm, target, decoding=decoding)
+        out.append((step, bufs["iters"][:step[3]].copy(), bufs["bit_errors"][:step[3]].copy()))
+    q.put((rank, out))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [("AWGN", -4.0, 0, 6000, 3, "BP", False), ("AWGN", -4.5, 5, 1, 2, "BP_MS", False),
+                                  ("BSC", 0.24, 2, 5001, 2, "BP", False), ("BEC", 0.8, 1, 3000, 2, "BP", True),
+                                  ("AWGN", -4.0, 11, 4000, 2, "BP", True)])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_frames_keep_their_results(case, world):
+    """Every frame of the sharded steps — whichever rank decoded it — has the iteration count and bit-error count
+    of the same frame in a one-rank run; the ranks' ranges tile the step without gaps."""
+    import libldpc_amd
+    chan, x, seed, target, steps, decoding, gen = case
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"/ldpc_amd_test_{os.getpid()}_s{world}"
+    ps = [ctx.Process(target=_shard_worker, args=(r, world, name, case, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = dict(q.get(timeout=300) for _ in range(world))
+    [p.join(timeout=60) for p in ps]
+    total = got[0][-1][0][0] + got[0][-1][0][1]  # frames covered by all steps
+    dec = libldpc_amd.HipDecoder(orc.H_TXT, orc.G_TXT if gen else "")
+    dec.set_bec_compat(True)
+    dec.stream_begin(chan, seed, x)
+    ref = dec.stream_decode(total, decoding=decoding)
+    pos = 0
+    for s in range(steps):
+        step0 = got[0][s][0]
+        assert step0[0] == pos
+        nxt = step0[0]
+        for r in range(world):
+            step, it, be = got[r][s]
+            assert step[:2] == step0[:2] and step[2] == nxt
+            assert np.array_equal(it, ref["iters"][step[2]:step[2] + step[3]]), (s, r)
+            assert np.array_equal(be, ref["bit_errors"][step[2]:step[2] + step[3]]), (s, r)
+            nxt += step[3]
+        assert nxt == step0[0] + step0[1]
+        pos = nxt
+    assert total >= target * steps * 0.9
+
+
+def _cli(args, out, extra=()):
+    exe = os.path.join(ROOT, "libldpc_amd", "ldpcsim")
+    subprocess.check_call([exe, orc.H_TXT, str(out)] + list(args) + list(extra), stdout=subprocess.DEVNULL)
+    return [ln.split()[:5] for ln in open(out).read().splitlines()] if os.path.exists(out) else []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["awgn_ms_sweep", "bsc", "awgn_bp", "bec_G", "awgn_bp_noearly_i10"])
+def test_ldpcsim_devices_equals_one_device(golden_sim, tmp_path, name):
+    """`ldpcsim --devices 0,0 --comm shm` (two rank processes sharing the GPU) and `--devices 0,0,0`: the result
+    file equals the one-process run's, line for line — counters, FER, BER and average iterations included."""
+    args = [orc.G_TXT if a == "<G>" else a for a in golden_sim["cli"][name]["args"]] + ["--bec-compat"]
+    one = _cli(args, tmp_path / "one.txt")
+    assert len(one) >= 2
+    for devs in ("0,0", "0,0,0"):
+        many = _cli(args, tmp_path / f"many{len(devs)}.txt", ("--devices", devs, "--comm", "shm"))
+        assert many == one, (name, devs)

@@ -11,8 +11,10 @@ single-frame case: one C-ABI decode() call (src/shared.cpp:47-65) per step, late
 
 N GPUs: one process per GPU.  Under `python -m torch.distributed.run` the ranks come from the environment; a plain
 `python bench.py --gpus N` starts the N rank processes itself (before anything in this process touches a GPU) and
-relays rank 0's line.  Ranks decode contiguous frame ranges of the same stream (weak scaling) and all-reduce the
-counters {frames, fec, bec, iters, converged} once per step over RCCL.
+relays rank 0's line.  Every step is one range of the single noise stream shared out over the ranks (weak scaling:
+N x 65 536 frames per step): each rank generates and scans only its own piece of the raw mt19937_64 stream, one RCCL
+all-gather of 8 bytes per rank places it in the pair sequence, and the counters {frames, fec, bec, iters, converged}
+are all-reduced once per step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
   roofline      the binding on-chip ceiling of the dominant kernel from SQ / TCC counters collected by rocprofv3 in
@@ -261,24 +263,44 @@ def run_rank(args, w):
     dec.set_bec_compat(w.get("bec_compat", False))
     stream = torch.cuda.current_stream().cuda_stream
     dev = torch.device("cuda", local_rank)
-    iters_d = torch.zeros(B, dtype=torch.int32, device=dev)
-    be_d = torch.zeros(B, dtype=torch.int32, device=dev)
+    cap = dec.shard_capacity(B * world, world) if world > 1 else B
+    iters_d = torch.zeros(cap, dtype=torch.int32, device=dev)
+    be_d = torch.zeros(cap, dtype=torch.int32, device=dev)
     out = {"iters": iters_d, "bit_errors": be_d}
-
-    # rank r owns the contiguous frame range [r*(W+K)*B, (r+1)*(W+K)*B) of the single stream (seed 0)
-    first, last = shard.frame_range(rank, world, (W + K) * B)
-    dec.stream_begin(w["channel"], 0, w["x"])
-    if first:
-        dec.stream_skip(first, stream)
     c = torch.zeros(5, dtype=torch.int64, device=dev)
 
+    # N > 1: every step is one range of the single noise stream (seed 0) shared out over the ranks by the library
+    # (ldpc_hip_stream_decode_sharded): each rank generates and scans only its own piece of the raw stream, one RCCL
+    # all-gather of the accepted-pair counts places it, and each rank decodes about B frames.  Weak scaling: the step
+    # grows with N.  The library's communicator is RCCL (its unique id travels over torch.distributed); the rehearsal
+    # on one GPU uses the host shared-memory transport, RCCL refuses two ranks on one device.
+    comm = None
+    if world > 1:
+        if os.environ.get("LDPC_BENCH_ONE_GPU"):
+            comm = libldpc_amd.Comm(rank, world, shm_name=f"/ldpc_bench_{os.environ.get('MASTER_PORT', '0')}")
+        else:
+            box = [libldpc_amd.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = libldpc_amd.Comm(rank, world, device=local_rank, unique_id=box[0])
+    dec.stream_begin(w["channel"], 0, w["x"])
+    span = [None, 0]  # frames covered by the timed steps: [first, end)
+
     def step():
-        dec.stream_decode(B, early_term=early, iterations=iters, decoding=w["decoding"], want=(), out=out, stream=stream)
-        # {frames, fec, bec, iters, converged} of the batch, summed by the library in one launch on the same stream
-        dec.batch_counters(iters_d.data_ptr(), be_d.data_ptr(), B, iters, early, c.data_ptr(), stream)
+        if comm is None:
+            dec.stream_decode(B, early_term=early, iterations=iters, decoding=w["decoding"], want=(), out=out, stream=stream)
+            n_own, st = B, (dec.stream_frame - B, B)
+        else:
+            _, s4 = dec.stream_decode_sharded(comm, B * world, early_term=early, iterations=iters, decoding=w["decoding"], want=(),
+                                              out=out, stream=stream)
+            n_own, st = s4[3], s4[:2]
+        if span[0] is None:
+            span[0] = st[0]
+        span[1] = st[0] + st[1]
+        # {frames, fec, bec, iters, converged} of the rank's frames, summed by the library in one launch on the same stream
+        dec.batch_counters(iters_d.data_ptr(), be_d.data_ptr(), n_own, iters, early, c.data_ptr(), stream)
         if dist is not None and backend != "nccl":
             return shard.reduce_counters(c.cpu(), dist).to(dev)
-        return shard.reduce_counters(c, dist)  # the one collective of the path: 5 x int64 over xGMI
+        return shard.reduce_counters(c, dist)  # the counters of the step: 5 x int64 over xGMI
 
     tot = torch.zeros(5, dtype=torch.int64, device=dev)
     for _ in range(W):  # same ops as the timed loop, so every kernel's code object is loaded beforehand
@@ -286,6 +308,7 @@ def run_rank(args, w):
     torch.cuda.synchronize()
     dec.last_ms(0), dec.last_ms(1)  # drop the warm-up launches' events
     tot.zero_()
+    span[0] = None
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -308,11 +331,15 @@ def run_rank(args, w):
     d = workloads.code_dims(w)
     # iterations executed = ret+1 for converged frames, ret otherwise
     edge_updates = (it_sum + conv) * d["nnz"]
+    if comm is not None:
+        comm.close()
     return ({"frames": frames, "dt": dt, "edge_updates": edge_updates, "kernel_ms": kernel_ms,
              "extra": {"fer": fec / frames, "ber": bec / (frames * d["nc"]), "avg_iter": it_sum / frames, "rng_ms_avg": rng_ms,
                        "counters": {"frames": frames, "fec": fec, "bec": bec, "iters": it_sum, "converged": conv},
-                       "frame_ranges": [list(shard.frame_range(r, world, (W + K) * B)) for r in range(world)],
-                       "residency": dec.residency}}, rank, world, dist)
+                       "timed_frame_span": span, "residency": dec.residency,
+                       "exchange": "none (one rank)" if world == 1 else ("host shared memory (one-GPU rehearsal)" if os.environ.get("LDPC_BENCH_ONE_GPU")
+                                                                        else "RCCL: u64 all-gather per step (pair counts) + 5 x int64 all-reduce (counters)")}},
+            rank, world, dist)
 
 
 def free_port():

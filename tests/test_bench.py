@@ -87,21 +87,21 @@ def test_bench_line_other_configs(cfg):
 
 @pytest.mark.gpu
 def test_bench_two_ranks_rehearsal():
-    """`python bench.py --gpus 2` starts two rank processes; both use cuda:0 here and reduce over gloo.  The summed
-    counters must equal single-process decodes of the two ranks' timed frame ranges."""
+    """`python bench.py --gpus 2` starts two rank processes; both use cuda:0 here (counters reduced over gloo, the
+    library's exchange over host shared memory).  The summed counters must equal a single-process decode of the
+    frames the timed steps covered."""
     import libldpc_amd
     B, K, W = 4096, 2, 1
     j = last_json(run_bench("--gpus", "2", "--steps", str(K), "--warmup", str(W), "--batch", str(B), "--no-cpu-baseline", "--no-pmc",
                             env={"LDPC_BENCH_ONE_GPU": "1", "LDPC_BENCH_BACKEND": "gloo"}))
-    assert j["n_gpus"] == 2 and j["config"]["frames_per_step"] == 2 * B
-    assert j["frame_ranges"] == [[0, (W + K) * B], [(W + K) * B, 2 * (W + K) * B]]
+    assert j["n_gpus"] == 2 and abs(j["config"]["frames_per_step"] - 2 * B) < 0.02 * B
+    first, end = j["timed_frame_span"]
+    assert first >= W * 2 * B * 0.98 and end - first == j["counters"]["frames"]
     dec = libldpc_amd.HipDecoder(os.path.join(ROOT, "tests", "golden", "h.txt"))
-    tot = np.zeros(5, np.int64)
-    for first, _ in j["frame_ranges"]:
-        dec.stream_begin("AWGN", 0, -4.0)
-        dec.stream_skip(first + W * B)
-        r = dec.stream_decode(K * B)
-        it, be = r["iters"].astype(np.int64), r["bit_errors"].astype(np.int64)
-        tot += np.array([K * B, (be > 0).sum(), be.sum(), it.sum(), (it < 50).sum()])
+    dec.stream_begin("AWGN", 0, -4.0)
+    dec.stream_skip(first)
+    r = dec.stream_decode(end - first)
+    it, be = r["iters"].astype(np.int64), r["bit_errors"].astype(np.int64)
+    tot = [end - first, int((be > 0).sum()), int(be.sum()), int(it.sum()), int((it < 50).sum())]
     c = j["counters"]
-    assert [c["frames"], c["fec"], c["bec"], c["iters"], c["converged"]] == tot.tolist()
+    assert [c["frames"], c["fec"], c["bec"], c["iters"], c["converged"]] == tot

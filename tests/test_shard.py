@@ -110,3 +110,26 @@ def test_ldpcsim_devices_equals_one_device(golden_sim, tmp_path, name):
     for devs in ("0,0", "0,0,0"):
         many = _cli(args, tmp_path / f"many{len(devs)}.txt", ("--devices", devs, "--comm", "shm"))
         assert many == one, (name, devs)
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_single_rank_and_sharded_step():
+    """The RCCL transport on the one GPU there is: librccl.so loads, a communicator of one rank initialises,
+    ncclAllGather carries the payload; and a sharded step over that communicator decodes the frames a plain
+    stream_decode decodes (the code path the multi-GPU runs take, with world = 1)."""
+    import libldpc_amd
+    comm = libldpc_amd.Comm(0, 1, device=0, unique_id=libldpc_amd.Comm.unique_id())
+    v = np.array([7, 2**63 + 5, 0, 123456789], np.uint64)
+    assert np.array_equal(comm.all_gather(v), v[None, :])
+    dec = libldpc_amd.HipDecoder(orc.H_TXT)
+    dec.stream_begin("AWGN", 0, -4.0)
+    got_it, got_be = [], []
+    for _ in range(3):
+        bufs, step = dec.stream_decode_sharded(comm, 5000)
+        assert step[0] == sum(len(x) for x in got_it) and step[2] == step[0] and step[3] == step[1]
+        got_it.append(bufs["iters"][:step[3]].copy()), got_be.append(bufs["bit_errors"][:step[3]].copy())
+    n = sum(len(x) for x in got_it)
+    dec.stream_begin("AWGN", 0, -4.0)
+    ref = dec.stream_decode(n)
+    assert np.array_equal(np.concatenate(got_it), ref["iters"]) and np.array_equal(np.concatenate(got_be), ref["bit_errors"])
+    comm.close()

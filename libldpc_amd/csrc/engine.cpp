@@ -520,6 +520,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
             a.ws_msg = static_cast<double *>(ws_msg_.reserve(8 * n * nnz));
             a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
             a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nnz));
+            a.ws_scr = plan_.max_cn_degree > kMaxCnDegree ? static_cast<double *>(ws_scr_.reserve(8 * n * nnz)) : nullptr;
             // resident frames per CU are bounded through a dummy LDS request so that the frames in flight
             // (256 CUs x frames/CU x state bytes) stay inside the 256 MiB Infinity Cache
             const uint64_t per_frame = 8ull * nnz + 8ull * nc + nnz;
@@ -530,13 +531,14 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
             check(launch_decode_mem(a, p.min_sum, plan_.max_cn_degree, occ_lds, s), "decode (memory-resident)");
         }
         else
-            throw std::runtime_error("check-node degree above " + std::to_string(kMaxCnDegree) + " is not supported");
+            throw std::runtime_error("code not supported by any decoder instantiation");
     };
     // Sum-product with early termination runs in likelihood-ratio form (detmath.h: no exp/log inside the
     // iteration); the few frames whose values leave the box that form can represent come back in a list and are
     // decoded from scratch by the LLR-domain form.  Which form finishes a frame depends on that frame's data
     // only, never on the batch it travels in.  (LDPC_AMD_NO_RATIO: experiments only — results change by ulps.)
-    if (!p.min_sum && p.early_term && p.iterations > 0 && !std::getenv("LDPC_AMD_NO_RATIO"))
+    // (codes with a check node wider than kMaxCnDegree run the LLR-domain form only; the oracle applies the same rule)
+    if (!p.min_sum && p.early_term && p.iterations > 0 && plan_.max_cn_degree <= kMaxCnDegree && !std::getenv("LDPC_AMD_NO_RATIO"))
     {
         uint32_t *redo = static_cast<uint32_t *>(redo_.reserve(4 * (n + 1)));
         check(hipMemsetAsync(redo, 0, 4, s), "redo count");
@@ -596,10 +598,10 @@ void Engine::run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t nc = plan_.nc;
     const uint64_t nct = static_cast<uint64_t>(plan_.nct);
-    if (((plan_.nnz + 15) / 16) * 16 + 2 * ((nc + 15) / 16) * 16 > 160 * 1024)
-        throw std::runtime_error("code too large for the LDS-resident erasure decoder");
+    const size_t state = static_cast<size_t>((plan_.nnz + 15) / 16) * 16 + 2 * ((nc + 15) / 16) * 16;
     OutStage st;
     BecArgs a{};
+    a.ws = state > 160 * 1024 ? static_cast<uint8_t *>(ws_msg_.reserve(n * state)) : nullptr; // beyond LDS: state in memory
     a.plan = dev_;
     a.iterations = p.iterations;
     a.early_term = p.early_term;

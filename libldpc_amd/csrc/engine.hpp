@@ -217,7 +217,7 @@ class Engine
     bool pairs_in_use_[2] = {false, false};
     int pp_ = 0;
     DeviceBuffer stage_in_, stage_iters_, stage_be_, stage_hard_, stage_llr_out_, stage_llr_in_, stage_cw_;
-    DeviceBuffer ws_msg_, ws_llr_, ws_hb_;
+    DeviceBuffer ws_msg_, ws_llr_, ws_hb_, ws_scr_;
     DeviceBuffer enc_snap_;
     uint64_t enc_snap_pos_ = 0;
     bool enc_snap_valid_ = false;

@@ -73,13 +73,83 @@ __device__ __forceinline__ void cn_update(double *m, int stride)
         m[j * stride] = v[j];
 }
 
+// A check node wider than the register tiles (degree > 16, memory-resident decoder only): the forward partial
+// results F[j] go through a per-frame scratch array laid out like the message array, the backward ones stay in a
+// register; same recursion, same order, same arithmetic as cn_core (E-domain form while every input is within
+// DM_SHARED_LIMIT and the node has at most 64 edges — the limit of the oracle's shared form — else the reference
+// expression term by term).  decoder.cpp:31-44.
+template <bool MINSUM>
+__device__ __noinline__ void cn_wide(double *m, double *scr, int stride, int d)
+{
+    bool shared = !MINSUM && d <= 64;
+    if (shared)
+    {
+        double amax = 0.0;
+        for (int j = 0; j < d; ++j)
+            amax = __builtin_fmax(amax, __builtin_fabs(m[j * stride]));
+        shared = amax <= DM_SHARED_LIMIT;
+    }
+    if (shared)
+    {
+        // partial results as (sign, E = e^-|L|): the sign rides in E's sign bit (E > 0)
+        auto enc = [](uint32_t sw, double e) { return dm_from_bits(dm_bits(e) | (static_cast<uint64_t>(sw & 0x80000000u) << 32)); };
+        double v0 = m[0];
+        double eF = dm_boxplus_exp(__builtin_fabs(v0));
+        uint32_t sF = DM_SIGN_WORD(v0);
+        scr[0] = enc(sF, eF);
+        for (int j = 1; j <= d - 2; ++j)
+        {
+            const double v = m[j * stride];
+            eF = dm_e_combine(eF, dm_boxplus_exp(__builtin_fabs(v)));
+            sF ^= DM_SIGN_WORD(v);
+            scr[j * stride] = enc(sF, eF); // F[j]
+        }
+        const double vl = m[(d - 1) * stride];
+        double eB = dm_boxplus_exp(__builtin_fabs(vl));
+        uint32_t sB = DM_SIGN_WORD(vl);
+        m[(d - 1) * stride] = dm_e_to_llr(sF, eF); // c2v[d-1] = F[d-2]
+        for (int j = d - 2; j >= 1; --j)
+        {
+            const double v = m[j * stride];
+            const double f = scr[(j - 1) * stride]; // F[j-1]
+            m[j * stride] = dm_e_to_llr(DM_SIGN_WORD(f) ^ sB, dm_e_combine(__builtin_fabs(f), eB));
+            eB = dm_e_combine(eB, dm_boxplus_exp(__builtin_fabs(v))); // B[j]
+            sB ^= DM_SIGN_WORD(v);
+        }
+        m[0] = dm_e_to_llr(sB, eB); // c2v[0] = B[1]
+        return;
+    }
+    double f = m[0];
+    scr[0] = f;
+    for (int j = 1; j <= d - 2; ++j)
+    {
+        f = boxplus<MINSUM>(f, m[j * stride]);
+        scr[j * stride] = f;
+    }
+    double bk = m[(d - 1) * stride];
+    m[(d - 1) * stride] = f;
+    for (int j = d - 2; j >= 1; --j)
+    {
+        const double v = m[j * stride];
+        m[j * stride] = boxplus<MINSUM>(scr[(j - 1) * stride], bk);
+        bk = boxplus<MINSUM>(bk, v);
+    }
+    m[0] = bk;
+}
+
 template <bool MINSUM, int MAXD>
-__device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane)
+__device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane, double *scratch = nullptr)
 {
     if (lane >= b.count)
         return;
     double *m = msg + b.off + lane;
     const int s = b.count;
+    if constexpr (MAXD >= 16)
+        if (b.degree > 16) // wave-uniform
+        {
+            cn_wide<MINSUM>(m, scratch + b.off + lane, s, b.degree);
+            return;
+        }
     switch (b.degree) // wave-uniform
     {
     case 2: cn_update<2, MINSUM>(m, s); break;
@@ -690,6 +760,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         llr = a.ws_llr + frame * nc;
         hb = a.ws_hb + frame * nnz;
     }
+    [[maybe_unused]] double *scratch = (!LDS_RESIDENT && a.ws_scr) ? a.ws_scr + frame * nnz : nullptr; // cn_wide
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -985,10 +1056,10 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     if (b1.count == kWaveSize && b0.count == kWaveSize &&
                         cn_pair<MINSUM, MAXD>(msg, b0.off, b1.off, b0.degree, b1.degree, lane))
                         continue;
-                    cn_block<MINSUM, MAXD>(msg, b0, lane);
+                    cn_block<MINSUM, MAXD>(msg, b0, lane, scratch);
                     if (b1.count == 0)
                         break;
-                    cn_block<MINSUM, MAXD>(msg, b1, lane);
+                    cn_block<MINSUM, MAXD>(msg, b1, lane, scratch);
                 }
             }
             else
@@ -997,7 +1068,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     const CnBlock b = cn_desc(w);
                     if (b.count == 0)
                         break;
-                    cn_block<MINSUM, MAXD>(msg, b, lane);
+                    cn_block<MINSUM, MAXD>(msg, b, lane, scratch);
                 }
             __syncthreads();
 
@@ -1172,13 +1243,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))
 //   erased VN of degree >= 3, edge j: x if any other input equals x, else 'E';
 //   erased VN of degree 2: the other input unchanged; degree 1: see deg1_compat.
 // ---------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t bec_state_bytes(int nnz, int nc)
+{
+    return static_cast<uint32_t>(((nnz + 15) / 16) * 16 + 2 * (((nc + 15) / 16) * 16));
+}
+
 __global__ __launch_bounds__(kThreads) void bec_kernel(const BecArgs a)
 {
     extern __shared__ double lds[];
     __shared__ int misc[4];
     const DevPlan &P = a.plan;
     const int nnz = P.nnz, nc = P.nc, nct = P.nct;
-    uint8_t *msg = reinterpret_cast<uint8_t *>(lds);
+    // state bytes: LDS, or device memory (a.ws: bec_state_bytes() per frame) for codes beyond 160 KB
+    uint8_t *msg = a.ws ? a.ws + static_cast<uint64_t>(blockIdx.x) * bec_state_bytes(nnz, nc) : reinterpret_cast<uint8_t *>(lds);
     uint8_t *sym = msg + ((nnz + 15) / 16) * 16;
     uint8_t *lout = sym + ((nc + 15) / 16) * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1602,9 +1679,9 @@ int launch_decode_mem(const DecodeArgs &a, bool min_sum, int max_cn_degree, uint
         return launch_decode<false, 4, kLlrMem>(a, min_sum, occupancy_lds, stream);
     if (max_cn_degree <= 8)
         return launch_decode<false, 8, kLlrMem>(a, min_sum, occupancy_lds, stream);
-    if (max_cn_degree <= 16)
-        return launch_decode<false, 16, kLlrMem>(a, min_sum, occupancy_lds, stream);
-    return hipErrorInvalidValue;
+    if (max_cn_degree > 16 && (!a.ws_scr || a.redo_list)) // wide nodes: scratch needed, no likelihood-ratio form
+        return hipErrorInvalidValue;
+    return launch_decode<false, 16, kLlrMem>(a, min_sum, occupancy_lds, stream);
 }
 
 int launch_batch_counters(const uint32_t *iters, const uint32_t *bit_errors, uint64_t n, uint32_t max_iters, int early_term,
@@ -1629,7 +1706,7 @@ int launch_bec(const BecArgs &a, void *stream)
 {
     if (a.n_frames == 0)
         return hipSuccess;
-    const uint32_t lds = ((a.plan.nnz + 15) / 16) * 16 + 2 * (((a.plan.nc + 15) / 16) * 16);
+    const uint32_t lds = a.ws ? 16u : bec_state_bytes(a.plan.nnz, a.plan.nc);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bec_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess)

@@ -71,6 +71,7 @@ struct DecodeArgs
     double *ws_msg;  // [n_frames][nnz]
     double *ws_llr;  // [n_frames][nc]
     uint8_t *ws_hb;  // [n_frames][nnz]
+    double *ws_scr;  // [n_frames][nnz] scratch of check nodes wider than 16 (nullptr when the code has none)
     // sum-product in likelihood-ratio form (detmath.h): when redo_list is set the launch runs that form and
     // appends the frames it could not finish to redo_list[atomicAdd(redo_count)]; a launch with redo_list_in /
     // redo_count_in set decodes exactly those frames (block b takes frame redo_list_in[b], b < *redo_count_in)
@@ -123,6 +124,7 @@ struct BecArgs
     uint8_t *hard;
     double *llr_out;     // symbol values 0, 1, 'E' widened to double
     double *llr_in_dump;
+    uint8_t *ws;         // per-frame state in device memory (codes whose nnz + 2 nc bytes exceed LDS), else nullptr
 };
 
 // All launchers enqueue on `stream` (hipStream_t passed as void*) and return a hipError_t as int.

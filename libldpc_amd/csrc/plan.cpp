@@ -151,8 +151,9 @@ Plan build_plan(const LdpcCode &code)
     p.lds_bytes = static_cast<size_t>(8) * p.nnz + static_cast<size_t>(8) * p.nc + ((p.nnz + 15) / 16) * 16 + 16;
     p.lds_ok = code.min_cn_degree() >= 2 && p.max_cn_degree <= kMaxLdsCnDegree && p.lds_bytes <= 160 * 1024 &&
                p.cn_blocks.size() < 0xFFFF && p.vn_blocks.size() < 0xFFFF;
-    p.hbm_ok = code.min_cn_degree() >= 2 && p.max_cn_degree <= kMaxCnDegree && p.cn_blocks.size() < 0xFFFF &&
-               p.vn_blocks.size() < 0xFFFF;
+    // the memory-resident decoder takes any check-node degree: up to kMaxCnDegree in registers, wider ones through a
+    // scratch array (kernels.hip, cn_wide)
+    p.hbm_ok = code.min_cn_degree() >= 2 && p.cn_blocks.size() < 0xFFFF && p.vn_blocks.size() < 0xFFFF;
     return p;
 }
 

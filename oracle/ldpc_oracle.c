@@ -645,7 +645,7 @@ static int dec_decode_ratio(dec_t *d)
         for (int i = 0; i < H->rows; ++i)
         {
             int cw = H->rptr[i + 1] - H->rptr[i];
-            if (cw > 64 || cw < 2)
+            if (cw > 16 || cw < 2) /* nodes wider than the kernels' register tiles: LLR-domain form only */
             {
                 escaped = 1;
                 break;

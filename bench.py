@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — the LDPC BP hot path on MI355X, one BASELINE.json configuration per run.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,2n,3,4,4n,5,5bec}]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,2n,2f,3,4,4n,5,5bec}]
 
 One "step" = one pass of the hot path over one batch of synthetic frames of the reference's noise stream
 mt19937_64(seed 0): noise generation, acceptance scan, fused channel + LLR init + flooding BP decode with syndrome
@@ -148,7 +148,7 @@ def cpu_baseline(w, budget_s=18.0):
     cores = os.cpu_count() or 1
     ref = os.path.join(ROOT, "oracle", "_ref", "ldpcsim_ref")
     d = workloads.code_dims(w)
-    guess = {"1": 700, "2": 700, "2n": 230, "3": 1100, "4": 90, "4n": 13, "5": 500, "5bec": 4300}[w["key"]]  # frames/s, one core
+    guess = {"1": 700, "2": 700, "2f": 700, "2n": 230, "3": 1100, "4": 90, "4n": 13, "5": 500, "5bec": 4300}[w["key"]]  # frames/s, one core
     out = os.path.join(tempfile.gettempdir(), f"ldpc_ref_{os.getpid()}.txt")
 
     def run_ref(frames, threads):
@@ -261,6 +261,7 @@ def run_rank(args, w):
     dec = libldpc_amd.HipDecoder(workloads.code_path(w), device=local_rank)
     dec.set_profiling(True)
     dec.set_bec_compat(w.get("bec_compat", False))
+    dec.set_fast_mode(w.get("fast", False))
     stream = torch.cuda.current_stream().cuda_stream
     dev = torch.device("cuda", local_rank)
     cap = dec.shard_capacity(B * world, world) if world > 1 else B
@@ -419,7 +420,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8" if w["channel"] == "BEC" else "f64",
+            "dtype": "u8" if w["channel"] == "BEC" else ("f32 (non-parity fast mode)" if w.get("fast") else "f64"),
             "data": "synthetic",
             "config": {"workload": w["name"], "baseline_config": args.config, "frames_per_step": m["frames"] // K,
                        "parallelism": f"frame-shard x{world}", "code": d},

@@ -111,6 +111,11 @@ const char *ldpc_hip_describe(ldpc_hip_ctx *ctx);
 /* BEC: 1 = reproduce the reference's out-of-bounds read for erased degree-1 variable nodes
    (they emit 0); 0 (default) = defined semantics, they emit an erasure */
 void ldpc_hip_set_bec_compat(ldpc_hip_ctx *ctx, int compat);
+/* 1 = NON-PARITY fast mode for sum-product decoding ("BP"): binary32 messages, LLRs clipped to +-27.7, hardware
+   reciprocal / log2 / exp2 (libldpc_amd/csrc/kernels_fast.hip).  Error rates differ from the reference's within what
+   profiles/ reports; iteration counts and decisions are not the reference's.  Off by default; min-sum and BEC ignore it.
+   The reference has no such mode in src/ (its legacy gpu/ simulator uses single precision, gpu/ldpc/ldpc.h). */
+void ldpc_hip_set_fast_mode(ldpc_hip_ctx *ctx, int on);
 
 /* decode n frames of given LLRs llr_in[n][nc] (column order, device or host). 0 on success. */
 int ldpc_hip_decode_batch(ldpc_hip_ctx *ctx, decoder_param dec, uint64_t n, const double *llr_in,

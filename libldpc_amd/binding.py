@@ -56,6 +56,7 @@ def load_library(path=LIB_PATH):
     L.ldpc_hip_destroy.argtypes = [vp]
     L.ldpc_hip_code_info.argtypes = [vp, ct.POINTER(ct.c_int64)]
     L.ldpc_hip_set_bec_compat.argtypes = [vp, i32]
+    L.ldpc_hip_set_fast_mode.argtypes = [vp, i32]
     L.ldpc_hip_decode_batch.restype = i32
     L.ldpc_hip_decode_batch.argtypes = [vp, decoder_param, u64, vp, ct.POINTER(ldpc_hip_out), vp]
     L.ldpc_hip_stream_begin.restype = i32
@@ -204,6 +205,10 @@ class HipDecoder:
 
     def set_bec_compat(self, on):
         self.lib.ldpc_hip_set_bec_compat(self.ctx, int(on))
+
+    def set_fast_mode(self, on):
+        """Opt-in NON-PARITY mode: sum-product with binary32 messages (include/ldpc_amd.h)."""
+        self.lib.ldpc_hip_set_fast_mode(self.ctx, int(on))
 
     def decode_batch(self, llr_in, early_term=True, iterations=50, decoding="BP",
                      want=("iters", "hard", "llr_out"), out=None, stream=None):

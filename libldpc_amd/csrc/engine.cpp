@@ -487,6 +487,33 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
     a.llr_out = st.route(out.llr_out, stage_llr_out_, 8 * n * nc);
     a.llr_in_dump = st.route(out.llr_in, stage_llr_in_, 8 * n * nc);
     prof_mark(0, s);
+    if (fast_mode && !p.min_sum)
+    {
+        // the caller asked for the non-parity binary32 sum-product; never chosen by itself
+        if (!fast_mode_supported(dev_, plan_.max_cn_degree) || plan_.has_isolated_vn)
+            throw std::runtime_error("fast mode: this code is outside what the binary32 kernel takes (check nodes up to degree 8, "
+                                     "nc <= 8192, LDS-resident, no isolated variable node)");
+        a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nc));
+        check(launch_decode_fast(a, plan_.max_cn_degree, s), "decode (fast mode, binary32)");
+        prof_mark(0, s);
+        if (a.mode == kModeAwgn && a.pairs_buffer >= 0 && ev_pairs_free_[a.pairs_buffer])
+        {
+            check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_free_[a.pairs_buffer]), s), "event");
+            pairs_in_use_[a.pairs_buffer] = true;
+        }
+        if (out.codeword)
+        {
+            if (a.codeword)
+                check(hipMemcpyAsync(out.codeword, a.codeword, n * nc,
+                                     is_device_ptr(out.codeword) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s), "codeword out");
+            else if (is_device_ptr(out.codeword))
+                check(hipMemsetAsync(out.codeword, 0, n * nc, s), "codeword out");
+            else
+                std::memset(out.codeword, 0, n * nc);
+        }
+        st.flush(s);
+        return;
+    }
     const auto launch = [&] {
         if (plan_.lds_ok)
         {

@@ -130,6 +130,8 @@ class Engine
     const Reg2Plan &reg2_plan() const { return reg2_plan_; }
     int device() const { return device_; }
     bool bec_deg1_compat = false;
+    // opt-in NON-PARITY fast mode: sum-product with binary32 messages (kernels_fast.hip); off by default
+    bool fast_mode = false;
 
     // ---- decode given LLRs (C-ABI decode(), shared.cpp:47-65, batched) ----
     void decode_llr(const DecParams &p, uint64_t n, const double *llr_in, const BatchOut &out, void *stream);

@@ -138,6 +138,9 @@ int launch_decode_mem(const DecodeArgs &a, bool min_sum, int max_cn_degree, uint
 int launch_decode_reg(const DecodeArgs &a, const DevRegPlan &r, bool min_sum, void *stream);
 // register-resident decoder, second form (same workspace requirements)
 int launch_decode_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, void *stream);
+// opt-in non-parity fast mode (kernels_fast.hip): sum-product with binary32 messages; a.ws_hb [n][nc] must be set
+bool fast_mode_supported(const DevPlan &p, int max_cn_degree);
+int launch_decode_fast(const DecodeArgs &a, int max_cn_degree, void *stream);
 int launch_bec(const BecArgs &a, void *stream);
 
 // ---- mt19937_64 on the device ----

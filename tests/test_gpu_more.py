@@ -396,3 +396,33 @@ def test_8k_bulk_bit_exact_vs_det_oracle(dec8k, h8k_file, x, ms, early, iters, n
     r = dec8k.stream_decode(n, early_term=early, iterations=iters, decoding="BP_MS" if ms else "BP", want=("iters", "bit_errors"))
     assert np.array_equal(r["iters"], it)
     assert np.array_equal(r["bit_errors"], be)
+
+
+def test_fast_mode_is_opt_in_and_close(dec):
+    """SURVEY §8f item 4: the NON-PARITY binary32 mode.  Off by default (everything above ran the binary64 kernels);
+    when switched on, the frame-error rate over 131 072 frames of the headline stream stays within 25 % of the
+    binary64 path's and at least 99.9 % of the frames reach the same verdict (error / no error)."""
+    import libldpc_amd
+    d = libldpc_amd.HipDecoder(orc.H_TXT)
+    n = 131072
+    d.stream_begin("AWGN", 0, -4.0)
+    ref = d.stream_decode(n)
+    d.set_fast_mode(True)
+    d.stream_begin("AWGN", 0, -4.0)
+    fast = d.stream_decode(n)
+    d.set_fast_mode(False)
+    d.stream_begin("AWGN", 0, -4.0)
+    again = d.stream_decode(1000)
+    assert np.array_equal(again["iters"], ref["iters"][:1000])  # switching it off restores the parity path
+    fer_ref, fer_fast = (ref["bit_errors"] > 0).mean(), (fast["bit_errors"] > 0).mean()
+    assert fer_ref > 5e-4 and abs(fer_fast - fer_ref) <= 0.25 * fer_ref, (fer_ref, fer_fast)
+    assert ((ref["bit_errors"] > 0) == (fast["bit_errors"] > 0)).mean() >= 0.999
+    assert abs(fast["iters"].mean() - ref["iters"].mean()) < 0.5
+    # min-sum ignores the switch
+    d.set_fast_mode(True)
+    d.stream_begin("AWGN", 0, -4.5)
+    a = d.stream_decode(2000, decoding="BP_MS")
+    d.set_fast_mode(False)
+    d.stream_begin("AWGN", 0, -4.5)
+    b = d.stream_decode(2000, decoding="BP_MS")
+    assert np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["bit_errors"], b["bit_errors"])

@@ -438,4 +438,30 @@ DM_FN double dm_frac_lambda2(dm_frac f, dm_frac g)
     return dm_ratio_div(num, den);
 }
 
+/*
+ * Hand-over (sum-product WITHOUT early termination).  With the syndrome check off a frame keeps iterating after it has
+ * converged and its LLRs grow until they leave the box the ratio form can hold; decoding such frames in the LLR domain
+ * from the start would pay its exp/log cost for every iteration.  Instead every frame starts in the ratio form and is
+ * handed over to the LLR-domain form — at an iteration boundary, with its messages converted by one logarithm each —
+ * as soon as a variable node's total lambda(total) has left [2^-DM_HANDOVER_EXP, 2^DM_HANDOVER_EXP) (|L| >= 152):
+ *
+ *     loop pass I:  check-node pass I (ratio form)
+ *                   a value has left the outer box (DM_RATIO_ESCAPED)       -> decode the frame again from scratch, LLR domain
+ *                   I == iterations                                         -> done
+ *                   a total of VN pass I-1 has left the inner box           -> c2v_e = -log(lambda_e) for every edge; the
+ *                                                                              LLR-domain form continues with VN pass I
+ *                   variable-node pass I (ratio form)
+ *
+ * The rule depends on the frame's own data only.  dm_handover_key(prod) is the exponent distance from 1, two-sided:
+ * prod >= 2^k or prod < 2^-k  <=>  key >= k << 20 (signed compare); anything that is not a positive normal number
+ * gives a large key.
+ */
+#define DM_HANDOVER_EXP 220
+DM_FN int32_t dm_handover_key(double prod)
+{
+    int32_t c = (int32_t)((uint32_t)(dm_bits(prod) >> 32) - 0x3FF00000u);
+    return c > ~c ? c : ~c;
+}
+#define DM_HANDOVER_DUE(key_max) ((key_max) >= (int32_t)(DM_HANDOVER_EXP << 20))
+
 #endif /* LDPC_AMD_DETMATH_H */

@@ -565,11 +565,20 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
     // decoded from scratch by the LLR-domain form.  Which form finishes a frame depends on that frame's data
     // only, never on the batch it travels in.  (LDPC_AMD_NO_RATIO: experiments only — results change by ulps.)
     // (codes with a check node wider than kMaxCnDegree run the LLR-domain form only; the oracle applies the same rule)
-    if (!p.min_sum && p.early_term && p.iterations > 0 && plan_.max_cn_degree <= kMaxCnDegree && !std::getenv("LDPC_AMD_NO_RATIO"))
+    // Without early termination the LDS-resident decoder still starts every frame in the ratio form and hands it over
+    // to the LLR-domain form at an iteration boundary when its totals near the edge of the box (detmath.h "Hand-over").
+    const bool handover = !p.early_term && plan_.lds_ok;
+    if (!p.min_sum && (p.early_term || handover) && p.iterations > 0 && plan_.max_cn_degree <= kMaxCnDegree &&
+        !std::getenv("LDPC_AMD_NO_RATIO"))
     {
-        uint32_t *redo = static_cast<uint32_t *>(redo_.reserve(4 * (n + 1)));
+        uint32_t *redo = static_cast<uint32_t *>(redo_.reserve(4 * (2 * n + 1)));
         check(hipMemsetAsync(redo, 0, 4, s), "redo count");
         a.redo_count = redo, a.redo_list = redo + 1;
+        if (handover)
+        {
+            a.redo_iter = redo + 1 + n;
+            a.ws_handover = static_cast<double *>(ws_msg_.reserve(8 * n * nnz));
+        }
 #ifdef LDPC_AMD_PHASE_TRACE
         uint64_t *tr = nullptr;
         if (std::getenv("LDPC_AMD_PHASE_TRACE")) // debug build: per-wave phase timers of the first 2048 frames -> file
@@ -595,11 +604,13 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
             a.phase_trace = nullptr;
         }
 #endif
-        a.redo_count = nullptr, a.redo_list = nullptr;
+        a.redo_count = nullptr, a.redo_list = nullptr, a.redo_iter = nullptr;
         a.redo_count_in = redo, a.redo_list_in = redo + 1;
+        if (handover)
+            a.redo_iter_in = redo + 1 + n;
     }
     launch();
-    a.redo_count_in = nullptr, a.redo_list_in = nullptr;
+    a.redo_count_in = nullptr, a.redo_list_in = nullptr, a.redo_iter_in = nullptr, a.ws_handover = nullptr;
     prof_mark(0, s);
     if (a.mode == kModeAwgn && a.pairs_buffer >= 0 && ev_pairs_free_[a.pairs_buffer])
     {

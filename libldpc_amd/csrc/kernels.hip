@@ -720,22 +720,31 @@ constexpr int kMaxVnBlocksInRegs = 8;
 // messages lambda = e^-L, the input LLRs are kept as lambda.  A frame whose values leave the representable box
 // is not finished here: its index goes to a.redo_list and the LLR-domain instantiation decodes it from scratch
 // in a second launch (a.redo_list_in / a.redo_count_in).
-template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO>
+// HANDOVER (RATIO only, used without early termination): a frame whose variable-node totals approach the edge of the
+// box is handed to the LLR-domain instantiation at an iteration boundary, its messages converted by one logarithm each
+// (detmath.h "Hand-over"): it is appended to a.redo_list with the iteration to resume at (a.redo_iter) and its c2v
+// messages go to a.ws_handover.  The LLR-domain instantiation resumes such frames (a.redo_iter_in / a.ws_handover).
+template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO, bool HANDOVER = false>
 __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 {
     static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
+    static_assert(!HANDOVER || RATIO, "the hand-over leaves the ratio form");
     extern __shared__ double lds[];
     __shared__ int misc[4];
     __shared__ int votes[2][kDecodeWaves];
     const DevPlan &P = a.plan;
     const int nnz = P.nnz, nc = P.nc;
     uint64_t frame = blockIdx.x;
+    uint32_t resume_at = 0xFFFFFFFFu; // LLR-domain second pass: iteration a handed-over frame resumes at (else: from scratch)
     if (a.redo_count_in) // second pass: only the frames the ratio form handed back
     {
         if (blockIdx.x >= *uniform_table(a.redo_count_in))
             return;
         frame = uniform_table(a.redo_list_in)[blockIdx.x];
+        if (a.redo_iter_in)
+            resume_at = uniform_table(a.redo_iter_in)[blockIdx.x];
     }
+    [[maybe_unused]] const bool resuming = !RATIO && resume_at != 0xFFFFFFFFu;
     double *msg, *llr;
     uint8_t *hb;
     if constexpr (LDS_RESIDENT)
@@ -792,6 +801,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 
     const auto my_vn = uniform_table(P.vn_work + wave * P.vn_work_stride);
     uint32_t escaped = 0; // RATIO: running maximum of dm_ratio_key over the frame's checked values (detmath.h)
+    [[maybe_unused]] int32_t ho_key = 0; // HANDOVER: running maximum of dm_handover_key over the variable-node totals
     if constexpr (RATIO && LLR_MODE != kLlrRegs)
     {
         // input LLRs become lambda = e^-L in place (isolated variable nodes keep their LLR: nothing multiplies it)
@@ -890,13 +900,20 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         }
     };
 
-    // ---- v2c initialisation: decoder.cpp:16-19 ----
-    for_my_vn_blocks([&](const VnBlock &b, double L) {
-        const uint32_t *idx = P.vn_slot + b.idx_off + lane;
-        const double v0 = RATIO ? dm_ratio_div(1.0, L) : L; // RATIO: L is lambda(L_ch), the first v2c is rho(L_ch)
-        for (int p = 0; p < b.degree; ++p)
-            msg[idx[p * b.count]] = v0;
-    });
+    // ---- v2c initialisation: decoder.cpp:16-19 (a handed-over frame: its c2v messages of iteration resume_at) ----
+    if (resuming)
+    {
+        const double *src = a.ws_handover + static_cast<uint64_t>(blockIdx.x) * nnz;
+        for (int e = tid; e < nnz; e += kThreads)
+            msg[e] = src[e];
+    }
+    else
+        for_my_vn_blocks([&](const VnBlock &b, double L) {
+            const uint32_t *idx = P.vn_slot + b.idx_off + lane;
+            const double v0 = RATIO ? dm_ratio_div(1.0, L) : L; // RATIO: L is lambda(L_ch), the first v2c is rho(L_ch)
+            for (int p = 0; p < b.degree; ++p)
+                msg[idx[p * b.count]] = v0;
+        });
     __syncthreads();
 
     double *out_llr = WANT_LLR ? a.llr_out + frame * nc : nullptr;
@@ -935,7 +952,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     bad |= cn_block_ratio<MAXD>(msg, b0, lane) | cn_block_ratio<MAXD>(msg, b1, lane);
             }
             const int ph = I & 1;
-            const int wave_vote = (__ballot(bad != 0) != 0) | ((__ballot(DM_RATIO_ESCAPED(escaped)) != 0) << 1);
+            int wave_vote = (__ballot(bad != 0) != 0) | ((__ballot(DM_RATIO_ESCAPED(escaped)) != 0) << 1);
+            if constexpr (HANDOVER)
+                wave_vote |= (__ballot(DM_HANDOVER_DUE(ho_key)) != 0) << 2;
             if (lane == 0)
                 votes[ph][wave] = wave_vote;
             PHASE_TICK(tr_cn)
@@ -956,20 +975,46 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             if (any & 2) // checked before the syndrome: an escaped frame's hard decisions mean nothing
             {
                 if (tid == 0)
-                    a.redo_list[atomicAdd(a.redo_count, 1u)] = static_cast<uint32_t>(frame);
+                {
+                    const uint32_t pos = atomicAdd(a.redo_count, 1u);
+                    a.redo_list[pos] = static_cast<uint32_t>(frame);
+                    if constexpr (HANDOVER)
+                        a.redo_iter[pos] = 0xFFFFFFFFu; // from scratch
+                }
                 return;
             }
-            if (I > 0 && !(any & 1)) // decoder.cpp:66-72 after VN pass I-1
+            if (I > 0 && a.early_term && !(any & 1)) // decoder.cpp:66-72 after VN pass I-1
             {
                 --I;
                 break;
             }
             if (I == a.iterations)
                 break;
+            if constexpr (HANDOVER)
+                if (any & 4) // a total of VN pass I-1 left the inner box: the LLR-domain form continues with VN pass I
+                {
+                    if (tid == 0)
+                    {
+                        const uint32_t pos = atomicAdd(a.redo_count, 1u);
+                        a.redo_list[pos] = static_cast<uint32_t>(frame);
+                        a.redo_iter[pos] = I;
+                        misc[1] = static_cast<int>(pos);
+                    }
+                    __syncthreads();
+                    double *dst = a.ws_handover + static_cast<uint64_t>(static_cast<uint32_t>(misc[1])) * nnz;
+                    for (int e = tid; e < nnz; e += kThreads)
+                        dst[e] = 0.0 - dm_log(__builtin_fabs(msg[e])); // c2v of iteration I: lambda -> LLR (sign bit: a decision)
+                    return;
+                }
             // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
             if constexpr (LLR_MODE == kLlrRegs)
             {
                 auto put_llr = [&](const VnBlock &b, double prod) {
+                    if constexpr (HANDOVER)
+                    {
+                        const int32_t k = dm_handover_key(prod);
+                        ho_key = k > ho_key ? k : ho_key;
+                    }
                     if constexpr (WANT_LLR)
                         out_llr[P.rank_col[b.first + lane]] = 0.0 - dm_log(prod);
                 };
@@ -1032,6 +1077,11 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     if (b.degree == 0)
                         return;
                     const double prod = vn_block_ratio(msg, P.vn_slot + b.idx_off + lane, b.count, b.degree, lam, escaped);
+                    if constexpr (HANDOVER)
+                    {
+                        const int32_t k = dm_handover_key(prod);
+                        ho_key = k > ho_key ? k : ho_key;
+                    }
                     if constexpr (WANT_LLR)
                         out_llr[P.rank_col[b.first + lane]] = 0.0 - dm_log(prod);
                 });
@@ -1043,10 +1093,15 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     }
     else
     {
+        if (resuming)
+            I = resume_at;
         while (I < a.iterations)
         {
-            // ---- CN pass: decoder.cpp:25-45 ----
-            if constexpr (MINSUM) // latency-bound: full blocks two at a time (one LDS round trip for both)
+            // ---- CN pass: decoder.cpp:25-45 (a handed-over frame arrives with the c2v messages of its first pass) ----
+            if (resuming && I == resume_at)
+            {
+            }
+            else if constexpr (MINSUM) // latency-bound: full blocks two at a time (one LDS round trip for both)
             {
                 for (int w = 0; w < P.cn_work_stride; w += 2)
                 {
@@ -1219,6 +1274,12 @@ template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE,
 __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 {
     decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO>(a);
+}
+
+template <bool WANT_LLR, int MAXD, int LLR_MODE>
+__global__ __launch_bounds__(kThreads) void decode_kernel_handover(const DecodeArgs a)
+{
+    decode_body<false, WANT_LLR, true, MAXD, LLR_MODE, true, true>(a);
 }
 
 // The same body compiled for five waves per SIMD (at most 96 VGPRs): the instantiations that sit at that boundary
@@ -1604,7 +1665,11 @@ int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *s
 {
     const bool want_llr = a.llr_out != nullptr;
     const bool ratio = a.redo_list != nullptr;
-    if (ratio && (min_sum || !a.early_term || a.iterations == 0 || !a.redo_count || a.redo_count_in))
+    // without early termination the ratio form runs with the hand-over to the LLR-domain form (detmath.h "Hand-over")
+    const bool handover = ratio && !a.early_term;
+    if (ratio && (min_sum || a.iterations == 0 || !a.redo_count || a.redo_count_in || (handover && (!a.redo_iter || !a.ws_handover))))
+        return hipErrorInvalidValue;
+    if (a.redo_iter_in && !a.ws_handover)
         return hipErrorInvalidValue;
     void (*k)(const DecodeArgs) = nullptr;
     if (min_sum)
@@ -1628,6 +1693,11 @@ int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *s
             else if (ratio)
                 k = decode_kernel_w5<false, false, LDS_RESIDENT, MAXD, LLR_MODE, true>;
         }
+    if constexpr (LDS_RESIDENT)
+        if (handover)
+            k = want_llr ? decode_kernel_handover<true, MAXD, LLR_MODE> : decode_kernel_handover<false, MAXD, LLR_MODE>;
+    if (handover && !LDS_RESIDENT)
+        return hipErrorInvalidValue; // (the memory-resident decoder runs the LLR-domain form when early termination is off)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes));
     if (e != hipSuccess)

@@ -79,6 +79,12 @@ struct DecodeArgs
     uint32_t *redo_count;
     const uint32_t *redo_list_in;
     const uint32_t *redo_count_in;
+    // hand-over (sum-product without early termination, detmath.h "Hand-over"): redo_iter[pos] = iteration the frame
+    // redo_list[pos] resumes at in the LLR domain (0xFFFFFFFF: decode it from scratch), ws_handover[pos][nnz] = its c2v
+    // messages as LLRs, in message-slot order
+    uint32_t *redo_iter;
+    const uint32_t *redo_iter_in;
+    double *ws_handover;
     uint64_t *phase_trace; // debug builds with -DLDPC_AMD_PHASE_TRACE only: [2048 frames of mid-launch][4 waves][8 values]
 };
 

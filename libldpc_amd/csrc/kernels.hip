@@ -905,7 +905,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     {
         const double *src = a.ws_handover + static_cast<uint64_t>(blockIdx.x) * nnz;
         for (int e = tid; e < nnz; e += kThreads)
-            msg[e] = src[e];
+            msg[e] = 0.0 - dm_log(__builtin_fabs(src[e])); // lambda -> LLR: one logarithm per message
     }
     else
         for_my_vn_blocks([&](const VnBlock &b, double L) {
@@ -1003,7 +1003,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     __syncthreads();
                     double *dst = a.ws_handover + static_cast<uint64_t>(static_cast<uint32_t>(misc[1])) * nnz;
                     for (int e = tid; e < nnz; e += kThreads)
-                        dst[e] = 0.0 - dm_log(__builtin_fabs(msg[e])); // c2v of iteration I: lambda -> LLR (sign bit: a decision)
+                        dst[e] = msg[e]; // c2v of iteration I as lambda (sign bit: a decision); the resuming kernel takes the logarithm
                     return;
                 }
             // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 }
 
 template <bool WANT_LLR, int MAXD, int LLR_MODE>
-__global__ __launch_bounds__(kThreads) void decode_kernel_handover(const DecodeArgs a)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void decode_kernel_handover(const DecodeArgs a)
 {
     decode_body<false, WANT_LLR, true, MAXD, LLR_MODE, true, true>(a);
 }

@@ -81,7 +81,7 @@ struct DecodeArgs
     const uint32_t *redo_count_in;
     // hand-over (sum-product without early termination, detmath.h "Hand-over"): redo_iter[pos] = iteration the frame
     // redo_list[pos] resumes at in the LLR domain (0xFFFFFFFF: decode it from scratch), ws_handover[pos][nnz] = its c2v
-    // messages as LLRs, in message-slot order
+    // messages as the ratio form left them (lambda, a decision in the sign bit), in message-slot order
     uint32_t *redo_iter;
     const uint32_t *redo_iter_in;
     double *ws_handover;

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, in one pass on the GPU box (through gpurun):
+#   tools/collect_round.sh gpurun_out/rN
+# then here:  python tools/summarize_profiles.py gpurun_out/rN rN
+#   - bench.py lines of every BASELINE configuration (with roofline + cpu_baseline)            -> configs.jsonl
+#   - rocprofv3 --kernel-trace --stats of the default bench.py command                        -> stats/
+#   - per-configuration counter passes (tools/profile_config.sh: SQ sets, FETCH_SIZE, WRITE_SIZE, stats)
+#   - the fast-mode error-rate report (tools/fast_mode_report.py)
+set -o pipefail
+out=${1:?output directory}
+mkdir -p "$out"
+export TMPDIR=/tmp
+: > "$out/configs.jsonl"
+for c in 2 1 3 4 5 5bec 2n 4n 2f; do
+    timeout -k 10 300 python3 bench.py --config $c --steps 40 --warmup 10 2> "$out/bench_cfg$c.err" | tail -1 >> "$out/configs.jsonl" || echo "bench config $c failed"
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/stats" -o run --output-format csv -- \
+    python3 bench.py --steps 10 --warmup 10 --no-cpu-baseline --no-pmc > "$out/bench_stats.log" 2>&1 || echo "stats pass failed"
+for c in 2 3 4 5 5bec 2n 4n 2f; do
+    tools/profile_config.sh "$out" $c 3 || echo "profile of config $c failed"
+done
+timeout -k 10 600 python3 tools/fast_mode_report.py > "$out/fast_mode_report.jsonl" 2> "$out/fast_mode_report.err" || echo "fast mode report failed"
+echo "round collected in $out"

@@ -390,9 +390,21 @@ __device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b,
 // VN update of one node in likelihood-ratio form, fully unrolled for degree DV (all loads in flight at once):
 // lambda(total) = lam * prod_p lambda(c2v_p) in column file order; v2c_p = lambda(c2v_p) / lambda(total).
 // Returns lambda(total); the hard decision (total LLR <= 0) goes into the sign bit of every v2c written.
+// A degree-1 node (a leaf) is special: out - c2v = L_ch, so its v2c message is the channel ratio rho_ch itself — no
+// division, nothing to range-check; `lam` is then rho_ch, the decision total <= 0 is taken as lambda(c2v) >= rho_ch, and
+// the value returned (for the LLR output only) is lambda(total) = lambda(c2v) / rho_ch.
+__device__ __forceinline__ double vn_leaf_ratio(double *msg, uint32_t slot, double rho)
+{
+    const double c = __builtin_fabs(msg[slot]);
+    msg[slot] = with_sign(rho, c >= rho ? 0x80000000u : 0u);
+    return dm_ratio_div(c, rho); // dead code unless the caller wants the LLR
+}
+
 template <int DV>
 __device__ __forceinline__ double vn_update_ratio(double *msg, const uint32_t *idx, int count, double lam, uint32_t &escaped)
 {
+    if constexpr (DV == 1)
+        return vn_leaf_ratio(msg, idx[0], lam);
     uint32_t s[DV];
     double c[DV];
 #pragma unroll
@@ -430,6 +442,8 @@ __device__ __forceinline__ double vn_small_ratio(double *msg, uint32_t packed, d
     static_assert(DV >= 1 && DV <= 2, "register-held slot indices");
     asm volatile("" : "+v"(packed)); // unpack here, every iteration: the packed word is what stays live
     const uint32_t sl[2] = {packed & 0xFFFFu, packed >> 16};
+    if constexpr (DV == 1)
+        return vn_leaf_ratio(msg, sl[0], lam);
     double c[DV];
 #pragma unroll
     for (int p = 0; p < DV; ++p)
@@ -461,6 +475,13 @@ __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, 
 #pragma unroll
     for (int p = 0; p < DV; ++p)
         ca[p] = __builtin_fabs(msg[sa[p]]), cb[p] = __builtin_fabs(msg[sb[p]]);
+    if constexpr (DV == 1) // two leaves: la, lb are their channel ratios (vn_leaf_ratio)
+    {
+        msg[sa[0]] = with_sign(la, ca[0] >= la ? 0x80000000u : 0u);
+        msg[sb[0]] = with_sign(lb, cb[0] >= lb ? 0x80000000u : 0u);
+        pa = dm_ratio_div(ca[0], la), pb = dm_ratio_div(cb[0], lb); // dead code unless the caller wants the LLRs
+        return;
+    }
     pa = la, pb = lb;
 #pragma unroll
     for (int p = 0; p < DV; ++p)
@@ -492,6 +513,8 @@ __device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32
         asm volatile("" : "+v"(pk[i]));
     }
     auto slot = [&](int p) { return (p & 1) ? pk[p >> 1] >> 16 : pk[p >> 1] & 0xFFFFu; };
+    if constexpr (DV == 1)
+        return vn_leaf_ratio(msg, slot(0), lam);
     double c[DV];
 #pragma unroll
     for (int p = 0; p < DV; ++p)
@@ -578,11 +601,13 @@ __device__ __forceinline__ void vn_ratio_pass2(double *msg, const uint32_t *idx,
 __device__ __forceinline__ double vn_block_ratio(double *msg, const uint32_t *idx, int count, int degree, double lam,
                                                  uint32_t &escaped)
 {
+    if (degree == 1) // a leaf takes its channel ratio rho_ch = 1 / lambda_ch (here, per call: the slow paths only)
+        return vn_update_ratio<1>(msg, idx, count, dm_ratio_div(1.0, lam), escaped);
     switch (degree) // wave-uniform
     {
 #define LDPC_VN(D) \
     case D: return vn_update_ratio<D>(msg, idx, count, lam, escaped);
-        LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
+        LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
 #undef LDPC_VN
     default: break;
     }
@@ -842,6 +867,8 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                             if (!(__builtin_fabs(my_llr[w]) <= DM_RATIO_LLR_LIMIT))
                                 escaped = ~0u;
                             my_llr[w] = dm_exp_clamped(0.0 - my_llr[w]);
+                            if (b.degree == 1) // a leaf keeps its channel ratio rho_ch instead (vn_leaf_ratio)
+                                my_llr[w] = dm_ratio_div(1.0, my_llr[w]);
                             const uint32_t *idx = P.vn_slot + b.idx_off + lane; // LDS-resident: every slot < 2^16
                             if (b.degree >= 1 && b.degree <= 2)
                                 my_idx[w] = idx[0] | (idx[(b.degree - 1) * b.count] << 16);
@@ -910,7 +937,8 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     else
         for_my_vn_blocks([&](const VnBlock &b, double L) {
             const uint32_t *idx = P.vn_slot + b.idx_off + lane;
-            const double v0 = RATIO ? dm_ratio_div(1.0, L) : L; // RATIO: L is lambda(L_ch), the first v2c is rho(L_ch)
+            // RATIO: L is lambda(L_ch) (kLlrRegs, a leaf: already rho(L_ch)), the first v2c is rho(L_ch)
+            const double v0 = RATIO ? ((LLR_MODE == kLlrRegs && b.degree == 1) ? L : dm_ratio_div(1.0, L)) : L;
             for (int p = 0; p < b.degree; ++p)
                 msg[idx[p * b.count]] = v0;
         });
@@ -1011,6 +1039,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             {
                 auto put_llr = [&](const VnBlock &b, double prod) {
                     if constexpr (HANDOVER)
+                        if (b.degree > 1) // (a leaf's total feeds nothing back)
                     {
                         const int32_t k = dm_handover_key(prod);
                         ho_key = k > ho_key ? k : ho_key;
@@ -1078,6 +1107,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                         return;
                     const double prod = vn_block_ratio(msg, P.vn_slot + b.idx_off + lane, b.count, b.degree, lam, escaped);
                     if constexpr (HANDOVER)
+                        if (b.degree > 1) // (a leaf's total feeds nothing back)
                     {
                         const int32_t k = dm_handover_key(prod);
                         ho_key = k > ho_key ? k : ho_key;

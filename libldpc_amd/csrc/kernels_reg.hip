@@ -214,6 +214,19 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
                     if constexpr (RATIO)
                         if (vb.degree > 0)
                         {
+                            if (vb.degree == 1)
+                            {
+                                // a leaf: its v2c is the channel ratio itself, the decision lambda(c2v) >= rho_ch
+                                // (kernels.hip, vn_leaf_ratio)
+                                const double c = col[0], rho = dm_ratio_div(1.0, llr[rank]);
+                                const uint8_t lbit = c >= rho;
+                                col[0] = rho;
+                                hcol[0] = lbit;
+                                hard[rank] = lbit;
+                                if constexpr (WANT_LLR)
+                                    out_llr[P.rank_col[rank]] = 0.0 - dm_log(dm_ratio_div(c, rho));
+                                continue;
+                            }
                             // lambda(total) = lambda(L_ch) * prod lambda(c2v_p), in column file order
                             double prod = llr[rank];
                             if (vb.degree <= 3)

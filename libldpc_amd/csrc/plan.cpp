@@ -242,6 +242,11 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
     if (code.min_cn_degree() < 2 || plan.max_cn_degree > maxd || n_cb > kc * W || plan.has_isolated_vn || kc * maxd > 64 ||
         n_vb > W * (nv0 + nv1) || plan.nnz == 0)
         return r;
+    // a degree-1 variable node's v2c message is its channel ratio, not total x c2v (kernels.hip, vn_leaf_ratio): the totals
+    // form cannot express that; such codes take the messages form
+    for (const VnBlock &vb : plan.vn_blocks)
+        if (vb.degree < 2)
+            return r;
     const int cap[2] = {W * nv0, W * nv1};
     std::vector<int> rb[2]; // Plan VN-block ids per round
     long ent[2] = {0, 0};

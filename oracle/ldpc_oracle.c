@@ -702,6 +702,17 @@ static int dec_decode_ratio(dec_t *d)
                 d->co[i] = (uint8_t)(d->llr_in[i] <= 0);
                 continue;
             }
+            if (deg == 1)
+            {
+                /* a leaf: out - c2v = L_ch, so its v2c message is the channel ratio itself (no division, nothing to
+                   range-check); the decision total <= 0 is lambda_ch * lambda(c2v) >= 1, taken as lambda(c2v) >= rho_ch */
+                int e = H->cedge[H->cptr[i]];
+                double c = d->c2v[e], rho = 1.0 / lam[i];
+                d->co[i] = (uint8_t)(c >= rho);
+                d->llr_out[i] = 0.0 - dm_log(c / rho);
+                d->v2c[e] = rho;
+                continue;
+            }
             double prod = lam[i];
             for (int k = 0; k < deg; ++k)
             {

@@ -313,6 +313,39 @@ DM_FN double dm_boxplus(double x, double y)
 
 DM_FN double dm_e_combine(double ex, double ey) { return dm_ratio_div(ex + ey, DM_FMA(ex, ey, 1.0)); } /* E >= e^-600 */
 
+/* The same economy as dm_frac (below) in the E domain: a partial result over m >= 2 inputs is carried as the fraction
+   E = n / d and divided only where a message leaves the node,
+       first two inputs  a [+] b : n = a + b,           d = 1 + a b
+       one more input    f [+] c : n' = f.n + f.d c,    d' = f.d + f.n c
+       two partials      f [+] g : (f.n g.d + f.d g.n) / (f.d g.d + f.n g.n)
+   so a degree-D node costs D divisions instead of 3(D-2).  E <= 1: n and d at most double per step (no rescaling up to
+   the 64 inputs of the shared form), d >= 1, n >= e^-600. */
+typedef struct
+{
+    double n, d;
+} dm_efrac;
+DM_FN dm_efrac dm_efrac_first(double a, double b)
+{
+    dm_efrac f;
+    f.n = a + b;
+    f.d = DM_FMA(a, b, 1.0);
+    return f;
+}
+DM_FN dm_efrac dm_efrac_step(dm_efrac f, double c)
+{
+    dm_efrac g;
+    g.n = DM_FMA(f.d, c, f.n);
+    g.d = DM_FMA(f.n, c, f.d);
+    return g;
+}
+DM_FN double dm_efrac_e(dm_efrac f) { return dm_ratio_div(f.n, f.d); }
+DM_FN double dm_efrac_e2(dm_efrac f, dm_efrac g)
+{
+    double num = DM_FMA(f.n, g.d, f.d * g.n);
+    double den = DM_FMA(f.n, g.n, f.d * g.d);
+    return dm_ratio_div(num, den);
+}
+
 /* LLR of a partial result carried as (sign bit, E): s * (-log E); an exact zero comes out as +0.0, as in
    the reference where log(1) = +0.0 is added to a signed zero */
 DM_FN double dm_e_to_llr(uint32_t sign_word, double e)

@@ -17,7 +17,7 @@ __device__ __forceinline__ void cn_core(double (&v)[D])
 {
     if constexpr (!MINSUM && D > 2) // a degree-2 node only swaps its two inputs: the generic code below
     {
-        // sum-product: the recursion is carried in E = e^-|L| (detmath.h, dm_e_combine / dm_e_to_llr) while
+        // sum-product: the recursion is carried in E = e^-|L| (detmath.h, dm_e_combine / dm_efrac / dm_e_to_llr) while
         // every input is within DM_SHARED_LIMIT; otherwise the direct box-plus below
         double amax = 0.0;
 #pragma unroll
@@ -25,7 +25,7 @@ __device__ __forceinline__ void cn_core(double (&v)[D])
             amax = __builtin_fmax(amax, __builtin_fabs(v[j]));
         if (amax <= DM_SHARED_LIMIT)
         {
-            double ev[D], eF[D], eB[D];
+            double ev[D];
             uint32_t sv[D], sF[D], sB[D];
 #pragma unroll
             for (int j = 0; j < D; ++j)
@@ -33,25 +33,46 @@ __device__ __forceinline__ void cn_core(double (&v)[D])
                 ev[j] = dm_boxplus_exp(__builtin_fabs(v[j]));
                 sv[j] = DM_SIGN_WORD(v[j]);
             }
-            eF[0] = ev[0], sF[0] = sv[0];
-            eB[D - 1] = ev[D - 1], sB[D - 1] = sv[D - 1];
+            sF[0] = sv[0], sB[D - 1] = sv[D - 1];
 #pragma unroll
             for (int j = 1; j < D - 1; ++j)
-            {
-                eF[j] = dm_e_combine(eF[j - 1], ev[j]);
                 sF[j] = sF[j - 1] ^ sv[j];
-            }
 #pragma unroll
             for (int j = D - 2; j >= 1; --j)
-            {
-                eB[j] = dm_e_combine(eB[j + 1], ev[j]);
                 sB[j] = sB[j + 1] ^ sv[j];
+            if constexpr (D == 3)
+            {
+                v[0] = dm_e_to_llr(sB[1], dm_e_combine(ev[2], ev[1]));
+                v[2] = dm_e_to_llr(sF[1], dm_e_combine(ev[0], ev[1]));
+                v[1] = dm_e_to_llr(sF[0] ^ sB[2], dm_e_combine(ev[0], ev[2]));
             }
-            v[0] = dm_e_to_llr(sB[1], eB[1]);
-            v[D - 1] = dm_e_to_llr(sF[D - 2], eF[D - 2]);
+            else
+            {
+                // D >= 4: partial results stay undivided fractions (detmath.h, dm_efrac): D divisions, not 3(D-2).
+                // F[j] = inputs 0..j (j >= 1), B[j] = inputs j..D-1 (j <= D-2)
+                dm_efrac F[D], B[D];
+                F[1] = dm_efrac_first(ev[0], ev[1]);
+                B[D - 2] = dm_efrac_first(ev[D - 1], ev[D - 2]);
 #pragma unroll
-            for (int j = 1; j < D - 1; ++j)
-                v[j] = dm_e_to_llr(sF[j - 1] ^ sB[j + 1], dm_e_combine(eF[j - 1], eB[j + 1]));
+                for (int j = 2; j <= D - 2; ++j)
+                    F[j] = dm_efrac_step(F[j - 1], ev[j]);
+#pragma unroll
+                for (int j = D - 3; j >= 1; --j)
+                    B[j] = dm_efrac_step(B[j + 1], ev[j]);
+                double o[D];
+                o[0] = dm_efrac_e(B[1]);
+                o[D - 1] = dm_efrac_e(F[D - 2]);
+                o[1] = dm_efrac_e(dm_efrac_step(B[2], ev[0]));             // F[0] [+] B[2]
+                o[D - 2] = dm_efrac_e(dm_efrac_step(F[D - 3], ev[D - 1])); // F[D-3] [+] B[D-1]
+#pragma unroll
+                for (int j = 2; j <= D - 3; ++j)
+                    o[j] = dm_efrac_e2(F[j - 1], B[j + 1]);
+                v[0] = dm_e_to_llr(sB[1], o[0]);
+                v[D - 1] = dm_e_to_llr(sF[D - 2], o[D - 1]);
+#pragma unroll
+                for (int j = 1; j < D - 1; ++j)
+                    v[j] = dm_e_to_llr(sF[j - 1] ^ sB[j + 1], o[j]);
+            }
             return;
         }
     }

@@ -547,7 +547,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
             a.ws_msg = static_cast<double *>(ws_msg_.reserve(8 * n * nnz));
             a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
             a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nnz));
-            a.ws_scr = plan_.max_cn_degree > kMaxCnDegree ? static_cast<double *>(ws_scr_.reserve(8 * n * nnz)) : nullptr;
+            a.ws_scr = plan_.max_cn_degree > kMaxCnDegree ? static_cast<double *>(ws_scr_.reserve(16 * n * nnz)) : nullptr;
             // resident frames per CU are bounded through a dummy LDS request so that the frames in flight
             // (256 CUs x frames/CU x state bytes) stay inside the 256 MiB Infinity Cache
             const uint64_t per_frame = 8ull * nnz + 8ull * nc + nnz;

@@ -79,7 +79,7 @@ __device__ __forceinline__ void cn_update(double *m, int stride)
 // DM_SHARED_LIMIT and the node has at most 64 edges — the limit of the oracle's shared form — else the reference
 // expression term by term).  decoder.cpp:31-44.
 template <bool MINSUM>
-__device__ __noinline__ void cn_wide(double *m, double *scr, int stride, int d)
+__device__ __noinline__ void cn_wide(double *m, double *scr, double *scr2, int stride, int d)
 {
     bool shared = !MINSUM && d <= 64;
     if (shared)
@@ -91,32 +91,49 @@ __device__ __noinline__ void cn_wide(double *m, double *scr, int stride, int d)
     }
     if (shared)
     {
-        // partial results as (sign, E = e^-|L|): the sign rides in E's sign bit (E > 0)
+        // partial results as (sign, fraction n/d of E = e^-|L|), detmath.h dm_efrac: the sign rides in n's sign bit (n > 0);
+        // F[j] (inputs 0..j) goes to scr[j] (n) and scr2[j] (d) for 1 <= j <= d-3, the backward partial stays in registers
         auto enc = [](uint32_t sw, double e) { return dm_from_bits(dm_bits(e) | (static_cast<uint64_t>(sw & 0x80000000u) << 32)); };
-        double v0 = m[0];
-        double eF = dm_boxplus_exp(__builtin_fabs(v0));
-        uint32_t sF = DM_SIGN_WORD(v0);
-        scr[0] = enc(sF, eF);
-        for (int j = 1; j <= d - 2; ++j)
+        const double v0 = m[0], v1 = m[stride];
+        const double e0 = dm_boxplus_exp(__builtin_fabs(v0));
+        dm_efrac F = dm_efrac_first(e0, dm_boxplus_exp(__builtin_fabs(v1)));
+        uint32_t sF = DM_SIGN_WORD(v0) ^ DM_SIGN_WORD(v1);
+        scr[stride] = enc(sF, F.n), scr2[stride] = F.d;
+        for (int j = 2; j <= d - 2; ++j)
         {
             const double v = m[j * stride];
-            eF = dm_e_combine(eF, dm_boxplus_exp(__builtin_fabs(v)));
+            F = dm_efrac_step(F, dm_boxplus_exp(__builtin_fabs(v)));
             sF ^= DM_SIGN_WORD(v);
-            scr[j * stride] = enc(sF, eF); // F[j]
+            if (j <= d - 3)
+                scr[j * stride] = enc(sF, F.n), scr2[j * stride] = F.d;
         }
-        const double vl = m[(d - 1) * stride];
-        double eB = dm_boxplus_exp(__builtin_fabs(vl));
-        uint32_t sB = DM_SIGN_WORD(vl);
-        m[(d - 1) * stride] = dm_e_to_llr(sF, eF); // c2v[d-1] = F[d-2]
-        for (int j = d - 2; j >= 1; --j)
+        const double vl = m[(d - 1) * stride], vl2 = m[(d - 2) * stride];
+        const double el = dm_boxplus_exp(__builtin_fabs(vl));
+        m[(d - 1) * stride] = dm_e_to_llr(sF, dm_efrac_e(F)); // c2v[d-1] = F[d-2]
+        // j = d-2: F[d-3] [+] raw input d-1
+        {
+            const double fn = scr[(d - 3) * stride];
+            dm_efrac f3;
+            f3.n = __builtin_fabs(fn), f3.d = scr2[(d - 3) * stride];
+            m[(d - 2) * stride] = dm_e_to_llr(DM_SIGN_WORD(fn) ^ DM_SIGN_WORD(vl), dm_efrac_e(dm_efrac_step(f3, el)));
+        }
+        dm_efrac B = dm_efrac_first(el, dm_boxplus_exp(__builtin_fabs(vl2))); // B[d-2]
+        uint32_t sB = DM_SIGN_WORD(vl) ^ DM_SIGN_WORD(vl2);
+        for (int j = d - 3; j >= 2; --j)
         {
             const double v = m[j * stride];
-            const double f = scr[(j - 1) * stride]; // F[j-1]
-            m[j * stride] = dm_e_to_llr(DM_SIGN_WORD(f) ^ sB, dm_e_combine(__builtin_fabs(f), eB));
-            eB = dm_e_combine(eB, dm_boxplus_exp(__builtin_fabs(v))); // B[j]
+            const double fn = scr[(j - 1) * stride]; // F[j-1], j-1 >= 1: a fraction
+            dm_efrac f;
+            f.n = __builtin_fabs(fn), f.d = scr2[(j - 1) * stride];
+            m[j * stride] = dm_e_to_llr(DM_SIGN_WORD(fn) ^ sB, dm_efrac_e2(f, B)); // F[j-1] [+] B[j+1]
+            B = dm_efrac_step(B, dm_boxplus_exp(__builtin_fabs(v)));                  // B[j]
             sB ^= DM_SIGN_WORD(v);
         }
-        m[0] = dm_e_to_llr(sB, eB); // c2v[0] = B[1]
+        // here B = B[2], sB its sign; j = 1: raw input 0 [+] B[2]; then B[1] = c2v[0]
+        m[stride] = dm_e_to_llr(DM_SIGN_WORD(v0) ^ sB, dm_efrac_e(dm_efrac_step(B, e0)));
+        B = dm_efrac_step(B, dm_boxplus_exp(__builtin_fabs(v1)));
+        sB ^= DM_SIGN_WORD(v1);
+        m[0] = dm_e_to_llr(sB, dm_efrac_e(B));
         return;
     }
     double f = m[0];
@@ -138,7 +155,7 @@ __device__ __noinline__ void cn_wide(double *m, double *scr, int stride, int d)
 }
 
 template <bool MINSUM, int MAXD>
-__device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane, double *scratch = nullptr)
+__device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane, double *scratch = nullptr, double *scratch2 = nullptr)
 {
     if (lane >= b.count)
         return;
@@ -147,7 +164,7 @@ __device__ __forceinline__ void cn_block(double *msg, const CnBlock b, int lane,
     if constexpr (MAXD >= 16)
         if (b.degree > 16) // wave-uniform
         {
-            cn_wide<MINSUM>(m, scratch + b.off + lane, s, b.degree);
+            cn_wide<MINSUM>(m, scratch + b.off + lane, scratch2 + b.off + lane, s, b.degree);
             return;
         }
     switch (b.degree) // wave-uniform
@@ -794,7 +811,8 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         llr = a.ws_llr + frame * nc;
         hb = a.ws_hb + frame * nnz;
     }
-    [[maybe_unused]] double *scratch = (!LDS_RESIDENT && a.ws_scr) ? a.ws_scr + frame * nnz : nullptr; // cn_wide
+    [[maybe_unused]] double *scratch = (!LDS_RESIDENT && a.ws_scr) ? a.ws_scr + frame * 2 * nnz : nullptr; // cn_wide
+    [[maybe_unused]] double *scratch2 = scratch ? scratch + nnz : nullptr;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1141,10 +1159,10 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     if (b1.count == kWaveSize && b0.count == kWaveSize &&
                         cn_pair<MINSUM, MAXD>(msg, b0.off, b1.off, b0.degree, b1.degree, lane))
                         continue;
-                    cn_block<MINSUM, MAXD>(msg, b0, lane, scratch);
+                    cn_block<MINSUM, MAXD>(msg, b0, lane, scratch, scratch2);
                     if (b1.count == 0)
                         break;
-                    cn_block<MINSUM, MAXD>(msg, b1, lane, scratch);
+                    cn_block<MINSUM, MAXD>(msg, b1, lane, scratch, scratch2);
                 }
             }
             else
@@ -1153,7 +1171,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     const CnBlock b = cn_desc(w);
                     if (b.count == 0)
                         break;
-                    cn_block<MINSUM, MAXD>(msg, b, lane, scratch);
+                    cn_block<MINSUM, MAXD>(msg, b, lane, scratch, scratch2);
                 }
             __syncthreads();
 

@@ -71,7 +71,7 @@ struct DecodeArgs
     double *ws_msg;  // [n_frames][nnz]
     double *ws_llr;  // [n_frames][nc]
     uint8_t *ws_hb;  // [n_frames][nnz]
-    double *ws_scr;  // [n_frames][nnz] scratch of check nodes wider than 16 (nullptr when the code has none)
+    double *ws_scr;  // [n_frames][2 nnz] scratch of check nodes wider than 16 (nullptr when the code has none)
     // sum-product in likelihood-ratio form (detmath.h): when redo_list is set the launch runs that form and
     // appends the frames it could not finish to redo_list[atomicAdd(redo_count)]; a launch with redo_list_in /
     // redo_count_in set decodes exactly those frames (block b takes frame redo_list_in[b], b < *redo_count_in)

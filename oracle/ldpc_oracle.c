@@ -374,7 +374,7 @@ static void dec_free(dec_t *d)
 static int cn_update_det_shared(dec_t *d, const int *cn, int cw)
 {
     enum { MAXD = 64 };
-    double v[MAXD], ev[MAXD], eF[MAXD], eB[MAXD];
+    double v[MAXD], ev[MAXD];
     uint32_t sv[MAXD], sF[MAXD], sB[MAXD];
     if (cw > MAXD || cw < 3) /* a degree-2 node only swaps its inputs: generic path */
         return 0;
@@ -389,22 +389,32 @@ static int cn_update_det_shared(dec_t *d, const int *cn, int cw)
         ev[j] = dm_boxplus_exp(fabs(v[j]));
         sv[j] = DM_SIGN_WORD(v[j]);
     }
-    eF[0] = ev[0], sF[0] = sv[0];
-    eB[cw - 1] = ev[cw - 1], sB[cw - 1] = sv[cw - 1];
+    sF[0] = sv[0], sB[cw - 1] = sv[cw - 1];
     for (int j = 1; j < cw - 1; ++j)
-    {
-        eF[j] = dm_e_combine(eF[j - 1], ev[j]);
         sF[j] = sF[j - 1] ^ sv[j];
-    }
     for (int j = cw - 2; j >= 1; --j)
-    {
-        eB[j] = dm_e_combine(eB[j + 1], ev[j]);
         sB[j] = sB[j + 1] ^ sv[j];
+    if (cw == 3)
+    {
+        d->c2v[cn[0]] = dm_e_to_llr(sB[1], dm_e_combine(ev[2], ev[1]));
+        d->c2v[cn[2]] = dm_e_to_llr(sF[1], dm_e_combine(ev[0], ev[1]));
+        d->c2v[cn[1]] = dm_e_to_llr(sF[0] ^ sB[2], dm_e_combine(ev[0], ev[2]));
+        return 1;
     }
-    d->c2v[cn[0]] = dm_e_to_llr(sB[1], eB[1]);
-    d->c2v[cn[cw - 1]] = dm_e_to_llr(sF[cw - 2], eF[cw - 2]);
-    for (int j = 1; j < cw - 1; ++j)
-        d->c2v[cn[j]] = dm_e_to_llr(sF[j - 1] ^ sB[j + 1], dm_e_combine(eF[j - 1], eB[j + 1]));
+    /* cw >= 4: partial results as undivided fractions (detmath.h, dm_efrac); F[j] = inputs 0..j, B[j] = inputs j..cw-1 */
+    dm_efrac Ff[MAXD], Bf[MAXD];
+    Ff[1] = dm_efrac_first(ev[0], ev[1]);
+    Bf[cw - 2] = dm_efrac_first(ev[cw - 1], ev[cw - 2]);
+    for (int j = 2; j <= cw - 2; ++j)
+        Ff[j] = dm_efrac_step(Ff[j - 1], ev[j]);
+    for (int j = cw - 3; j >= 1; --j)
+        Bf[j] = dm_efrac_step(Bf[j + 1], ev[j]);
+    d->c2v[cn[0]] = dm_e_to_llr(sB[1], dm_efrac_e(Bf[1]));
+    d->c2v[cn[cw - 1]] = dm_e_to_llr(sF[cw - 2], dm_efrac_e(Ff[cw - 2]));
+    d->c2v[cn[1]] = dm_e_to_llr(sF[0] ^ sB[2], dm_efrac_e(dm_efrac_step(Bf[2], ev[0])));
+    d->c2v[cn[cw - 2]] = dm_e_to_llr(sF[cw - 3] ^ sB[cw - 1], dm_efrac_e(dm_efrac_step(Ff[cw - 3], ev[cw - 1])));
+    for (int j = 2; j <= cw - 3; ++j)
+        d->c2v[cn[j]] = dm_e_to_llr(sF[j - 1] ^ sB[j + 1], dm_efrac_e2(Ff[j - 1], Bf[j + 1]));
     return 1;
 }
 

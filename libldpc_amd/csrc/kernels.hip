@@ -659,7 +659,7 @@ __device__ __forceinline__ double vn_block_ratio(double *msg, const uint32_t *id
 // VN update of one node in the LLR domain (decoder.cpp:48-64), unrolled for degree DV: every message is read once.
 // Returns the APP LLR; v2c_p = APP - c2v_p, the hard decision goes to the hard-bit array.
 template <int DV>
-__device__ __forceinline__ double vn_update_llr(double *msg, uint8_t *hb, const uint32_t *idx, int count, double L)
+__device__ __forceinline__ double vn_update_llr(double *msg, uint8_t *hb, const uint32_t *idx, int count, double L, bool store_hb)
 {
     uint32_t s[DV];
     double c[DV];
@@ -678,14 +678,15 @@ __device__ __forceinline__ double vn_update_llr(double *msg, uint8_t *hb, const 
     for (int p = 0; p < DV; ++p)
     {
         msg[s[p]] = out - c[p];
-        hb[s[p]] = bit;
+        if (store_hb) // (false: the decisions of this pass are not needed, see the loop)
+            hb[s[p]] = bit;
     }
     return out;
 }
 
 // two nodes (of two full blocks) of the same degree DV <= 2 in lock step
 template <int DV>
-__device__ __forceinline__ void vn_update_llr2(double *msg, uint8_t *hb, const uint32_t *idx0, const uint32_t *idx1, double L0,
+__device__ __forceinline__ void vn_update_llr2(bool store_hb, double *msg, uint8_t *hb, const uint32_t *idx0, const uint32_t *idx1, double L0,
                                                double L1, double &out0, double &out1)
 {
     uint32_t s0[DV], s1[DV];
@@ -706,17 +707,20 @@ __device__ __forceinline__ void vn_update_llr2(double *msg, uint8_t *hb, const u
     {
         msg[s0[p]] = out0 - c0[p];
         msg[s1[p]] = out1 - c1[p];
-        hb[s0[p]] = bit0;
-        hb[s1[p]] = bit1;
+        if (store_hb)
+        {
+            hb[s0[p]] = bit0;
+            hb[s1[p]] = bit1;
+        }
     }
 }
 
-__device__ __forceinline__ double vn_block_llr(double *msg, uint8_t *hb, const uint32_t *idx, int count, int degree, double L)
+__device__ __forceinline__ double vn_block_llr(double *msg, uint8_t *hb, const uint32_t *idx, int count, int degree, double L, bool store_hb)
 {
     switch (degree) // wave-uniform
     {
 #define LDPC_VN(D) \
-    case D: return vn_update_llr<D>(msg, hb, idx, count, L);
+    case D: return vn_update_llr<D>(msg, hb, idx, count, L, store_hb);
         LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
         LDPC_VN(9) LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15) LDPC_VN(16)
 #undef LDPC_VN
@@ -730,7 +734,8 @@ __device__ __forceinline__ double vn_block_llr(double *msg, uint8_t *hb, const u
     {
         const uint32_t sl = idx[p * count];
         msg[sl] = out - msg[sl];
-        hb[sl] = bit;
+        if (store_hb)
+            hb[sl] = bit;
     }
     return out;
 }
@@ -1176,10 +1181,15 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             __syncthreads();
 
             // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
+            // the per-edge hard bits feed the syndrome check and the outputs: without early termination only the
+            // last pass has to store them (one LDS byte store per edge and iteration less)
+            // (min-sum instantiations only: the sum-product instantiation's register allocation tips over with the flag,
+            // 128 -> 141 VGPRs, and it is arithmetic-bound anyway)
+            const bool store_hb = !MINSUM || a.early_term || I + 1 == a.iterations;
             auto vn_one = [&](const VnBlock &b, double L) {
                 if (lane >= b.count)
                     return;
-                const double out = vn_block_llr(msg, hb, P.vn_slot + b.idx_off + lane, b.count, b.degree, L);
+                const double out = vn_block_llr(msg, hb, P.vn_slot + b.idx_off + lane, b.count, b.degree, L, store_hb);
                 if constexpr (WANT_LLR)
                     out_llr[P.rank_col[b.first + lane]] = out;
             };
@@ -1205,9 +1215,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                         const uint32_t *i0 = P.vn_slot + b0.idx_off + lane, *i1 = P.vn_slot + b1.idx_off + lane;
                         double o0, o1;
                         if (b0.degree == 1)
-                            vn_update_llr2<1>(msg, hb, i0, i1, my_llr[w], my_llr[w + 1], o0, o1);
+                            vn_update_llr2<1>(store_hb, msg, hb, i0, i1, my_llr[w], my_llr[w + 1], o0, o1);
                         else
-                            vn_update_llr2<2>(msg, hb, i0, i1, my_llr[w], my_llr[w + 1], o0, o1);
+                            vn_update_llr2<2>(store_hb, msg, hb, i0, i1, my_llr[w], my_llr[w + 1], o0, o1);
                         if constexpr (WANT_LLR)
                         {
                             out_llr[P.rank_col[b0.first + lane]] = o0;

@@ -75,14 +75,39 @@ struct OutStage
         items.push_back({user, d, bytes});
         return static_cast<T *>(d);
     }
-    void flush(hipStream_t s)
+    // small results go through page-locked memory: a device-to-pageable copy is a blocking staged copy per call,
+    // which is most of a single-frame decode()'s latency
+    void flush(hipStream_t s, PinnedBuffer *pin = nullptr)
     {
+        size_t total = 0;
+        for (auto &i : items)
+            total += (i.bytes + 63) & ~size_t(63);
+        if (pin && total && total <= kPinnedLimit)
+        {
+            char *h = static_cast<char *>(pin->reserve(total));
+            size_t off = 0;
+            for (auto &i : items)
+            {
+                check(hipMemcpyAsync(h + off, i.dev, i.bytes, hipMemcpyDeviceToHost, s), "copy out");
+                off += (i.bytes + 63) & ~size_t(63);
+            }
+            check(hipStreamSynchronize(s), "sync");
+            off = 0;
+            for (auto &i : items)
+            {
+                std::memcpy(i.host, h + off, i.bytes);
+                off += (i.bytes + 63) & ~size_t(63);
+            }
+            items.clear();
+            return;
+        }
         for (auto &i : items)
             check(hipMemcpyAsync(i.host, i.dev, i.bytes, hipMemcpyDeviceToHost, s), "copy out");
         if (!items.empty())
             check(hipStreamSynchronize(s), "sync");
         items.clear();
     }
+    static constexpr size_t kPinnedLimit = 1 << 20;
 };
 
 // t^(J*2^m) mod phi, computed lazily once per process
@@ -105,6 +130,26 @@ const Gf2Poly &jump_poly(unsigned m)
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
+PinnedBuffer::~PinnedBuffer()
+{
+    if (ptr_)
+        (void)hipHostFree(ptr_);
+}
+
+void *PinnedBuffer::reserve(size_t bytes)
+{
+    if (bytes > size_)
+    {
+        if (ptr_)
+            check(hipHostFree(ptr_), "hipHostFree");
+        ptr_ = nullptr;
+        const size_t want = std::max<size_t>(bytes, 64 * 1024);
+        check(hipHostMalloc(&ptr_, want, hipHostMallocDefault), "hipHostMalloc");
+        size_ = want;
+    }
+    return ptr_;
+}
+
 DeviceBuffer::~DeviceBuffer()
 {
     if (ptr_)
@@ -317,6 +362,8 @@ Engine::~Engine()
     }
     if (rng_stream_)
         (void)hipStreamDestroy(static_cast<hipStream_t>(rng_stream_));
+    if (pin_in_ev_)
+        (void)hipEventDestroy(static_cast<hipEvent_t>(pin_in_ev_));
 }
 
 void Engine::set_profiling(bool on) { profiling_ = on; }
@@ -511,7 +558,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
             else
                 std::memset(out.codeword, 0, n * nc);
         }
-        st.flush(s);
+        st.flush(s, &pin_out_);
         return;
     }
     const auto launch = [&] {
@@ -628,7 +675,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         else
             std::memset(out.codeword, 0, n * nc);
     }
-    st.flush(s);
+    st.flush(s, &pin_out_);
 }
 
 void Engine::run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const uint8_t *codeword, void *stream)
@@ -667,7 +714,7 @@ void Engine::run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const 
         else
             std::memset(out.codeword, 0, n * nc);
     }
-    st.flush(s);
+    st.flush(s, &pin_out_);
 }
 
 // channel.cpp:44-60 for n consecutive frames (see EncodeArgs in kernels.hpp)
@@ -733,7 +780,24 @@ void Engine::decode_llr(const DecParams &p, uint64_t n, const double *llr_in, co
         else
         {
             void *d = stage_in_.reserve(bytes);
-            check(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s), "copy in");
+            const void *from = src;
+            if (bytes <= (1u << 20)) // small inputs through page-locked memory (see OutStage::flush)
+            {
+                if (!pin_in_ev_)
+                {
+                    hipEvent_t ev;
+                    check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+                    pin_in_ev_ = ev;
+                }
+                else
+                    check(hipEventSynchronize(static_cast<hipEvent_t>(pin_in_ev_)), "event"); // the previous copy out of the buffer is done
+                void *h = pin_in_.reserve(bytes);
+                std::memcpy(h, src, bytes);
+                from = h;
+            }
+            check(hipMemcpyAsync(d, from, bytes, hipMemcpyHostToDevice, s), "copy in");
+            if (from != src)
+                check(hipEventRecord(static_cast<hipEvent_t>(pin_in_ev_), s), "event");
             a.llr_in = static_cast<const double *>(d);
         }
         run_decode(a, p, o, m, stream);

@@ -97,6 +97,20 @@ class ChunkTable
     uint32_t pow_ready_ = 0; // power-of-two prefix obtained by doubling
 };
 
+// page-locked host memory for small transfers (single-frame decode(): the copies are latency, not bandwidth)
+class PinnedBuffer
+{
+  public:
+    PinnedBuffer() = default;
+    ~PinnedBuffer();
+    PinnedBuffer(const PinnedBuffer &) = delete;
+    PinnedBuffer &operator=(const PinnedBuffer &) = delete;
+    void *reserve(size_t bytes); // grow-only
+  private:
+    void *ptr_ = nullptr;
+    size_t size_ = 0;
+};
+
 // One mt19937_64(seed) stream: chunk start states by jump-ahead, raw words generated on demand.
 class MtStream
 {
@@ -220,6 +234,8 @@ class Engine
     int pp_ = 0;
     DeviceBuffer stage_in_, stage_iters_, stage_be_, stage_hard_, stage_llr_out_, stage_llr_in_, stage_cw_;
     DeviceBuffer ws_msg_, ws_llr_, ws_hb_, ws_scr_;
+    PinnedBuffer pin_in_, pin_out_;
+    void *pin_in_ev_ = nullptr; // hipEvent_t: the last host-to-device copy out of pin_in_
     DeviceBuffer enc_snap_;
     uint64_t enc_snap_pos_ = 0;
     bool enc_snap_valid_ = false;

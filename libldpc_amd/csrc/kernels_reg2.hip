@@ -201,6 +201,19 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
 
     double *out_llr = WANT_LLR ? a.llr_out + frame * nc : nullptr;
     uint32_t I = 0, result = 0;
+#ifdef LDPC_AMD_PHASE_TRACE
+    // per-wave cycles spent in each phase of the loop and waiting at its barrier (tools/phase_probe_reg2.py)
+    uint64_t ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_t = __builtin_amdgcn_s_memtime();
+    const uint64_t ph_entry = ph_t;
+#define REG2_TICK(k)                                          \
+    {                                                         \
+        const uint64_t n_ = __builtin_amdgcn_s_memtime();     \
+        ph[k] += n_ - ph_t;                                   \
+        ph_t = n_;                                            \
+    }
+#else
+#define REG2_TICK(k)
+#endif
     for (;;)
     {
         // (the same for the two address fields of the packed edge words: hoisted, they would cost 2*KC*MAXD registers)
@@ -245,7 +258,9 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
             const uint64_t any1 = __ballot(f & 1u), any2 = __ballot(f & 2u);
             if (lane == 0 && (any1 | any2))
                 atomicOr(&vote[I & 1], (any1 ? 1u : 0u) | (any2 ? 2u : 0u));
+            REG2_TICK(0)
             __syncthreads();
+            REG2_TICK(1)
             const uint32_t v = vote[I & 1];
             if (tid == 0)
                 vote[(I + 1) & 1] = 0;
@@ -276,7 +291,9 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
             for (int j = 0; j < MAXD; ++j)
                 if ((k * MAXD + j < 32 ? rm0l : rm0h) & (1u << ((k * MAXD + j) & 31)))
                     *lds_abs<double>((ew[k][j] >> scatter_shift) & scatter_mask) = m[k][j];
+        REG2_TICK(2)
         __syncthreads();
+        REG2_TICK(3)
         // ---- VN pass, APP and hard decision (decoder.cpp:48-64): totals of the two rounds ----
         auto vn_round = [&]<int... Is>(std::integer_sequence<int, Is...>, auto base) {
             (([&] {
@@ -335,19 +352,34 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
              ...);
         };
         vn_round(std::make_integer_sequence<int, NV0>{}, std::integral_constant<int, 0>{});
+        REG2_TICK(4)
         __syncthreads();
+        REG2_TICK(5)
 #pragma unroll
         for (int k = 0; k < KC; ++k)
 #pragma unroll
             for (int j = 0; j < MAXD; ++j)
                 if ((k * MAXD + j < 32 ? rm1l : rm1h) & (1u << ((k * MAXD + j) & 31)))
                     *lds_abs<double>((ew[k][j] >> scatter_shift) & scatter_mask) = m[k][j];
+        REG2_TICK(6)
         __syncthreads();
+        REG2_TICK(7)
         vn_round(std::make_integer_sequence<int, NV1>{}, std::integral_constant<int, NV0>{});
+        REG2_TICK(8)
         __syncthreads();
+        REG2_TICK(9)
         ++I;
     }
 
+#ifdef LDPC_AMD_PHASE_TRACE
+    if (a.phase_trace && frame >= 2048 && frame < 2048 + 256 && lane == 0)
+    {
+        uint64_t *o = a.phase_trace + ((frame - 2048) * W + wave) * 16;
+        for (int k = 0; k < 10; ++k)
+            o[k] = ph[k];
+        o[10] = ph_entry - 0, o[11] = __builtin_amdgcn_s_memtime() - ph_entry, o[12] = I;
+    }
+#endif
     // ---- outputs ----
     const bool ran = a.iterations > 0;
 #pragma unroll

@@ -359,6 +359,32 @@ DM_FN double dm_e_to_llr(uint32_t sign_word, double e)
 #define DM_SIGN_WORD(x) ((uint32_t)(dm_bits(x) >> 32))
 
 /* ------------------------------------------------------------------------------------------------
+ * Saturated check nodes.  Without early termination a converged frame keeps iterating and its LLRs double with every
+ * pass — 1e13 after 50 iterations of the (3,6) code, far beyond DM_SHARED_LIMIT — while the DIFFERENCES between the
+ * inputs of one check node stay of the order of the channel LLRs.  With mu = min_j |v_j| and E'_j = e^-(|v_j| - mu)
+ * the E-domain box-plus of two partial results (a e^-mu) and (b e^-mu) is  e^-mu (a + b) / (1 + e^-2mu a b).  Once
+ * mu >= DM_SAT_MIN = 40 the denominator differs from 1 by less than 64^2 e^-80 < 2^-103, and the recursion is a sum:
+ *
+ *     |c2v_j| = mu - log( sum_{i != j} E'_i ),        sign as in the E-domain form
+ *
+ * with the sums taken in the reference's order (F[j] = F[j-1] + E'_j, B[j] = B[j+1] + E'_j, F[j-1] + B[j+1]): d
+ * exponentials of small arguments, d logarithms and 3(d-2) additions for a degree-d node, where the chain of
+ * dm_boxplus costs 3(d-2) times two exponentials, a division and a logarithm — and it is the value of the reference's
+ * chain of box-pluses to within 2^-103 relative, before rounding.
+ * Rule (3 <= d <= 64, checked BEFORE the E-domain form): mu >= DM_SAT_MIN and max_j |v_j| - mu <= DM_SHARED_LIMIT,
+ * so that every E' is a normal number and every sum lies in [e^-600, 64].
+ * ------------------------------------------------------------------------------------------------ */
+#define DM_SAT_MIN 40.0
+DM_FN int dm_sat_applies(double mu, double amax) { return mu >= DM_SAT_MIN && amax - mu <= DM_SHARED_LIMIT; }
+DM_FN double dm_sat_e(double absv, double mu) { return dm_boxplus_exp(absv - mu); }
+DM_FN double dm_sat_llr(uint32_t sign_word, double mu, double sum)
+{
+    double mag = mu - dm_boxplus_log(sum);
+    double sd = dm_from_bits((uint64_t)(0x3FF00000u | (sign_word & 0x80000000u)) << 32); /* s as +-1.0 */
+    return DM_FMA(sd, mag, 0.0);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Likelihood-ratio form of the whole BP iteration (no exp/log inside the loop).
  *
  * With rho(L) = e^L and lambda(L) = e^-L the reference's two updates are, as real functions,

@@ -12,17 +12,54 @@
 namespace ldpc_amd
 {
 
+// Saturated check node (detmath.h, "Saturated check nodes"): every magnitude at least DM_SAT_MIN and within
+// DM_SHARED_LIMIT of the smallest one, mu.  F[j] = inputs 0..j, B[j] = inputs j..D-1, as sums of e^-(|v| - mu).
+template <int D>
+__device__ __forceinline__ void cn_saturated(double (&v)[D], double mu)
+{
+    double F[D], B[D];
+    uint32_t sv[D], sF[D], sB[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+    {
+        F[j] = dm_sat_e(__builtin_fabs(v[j]), mu); // E'_j for now
+        sv[j] = DM_SIGN_WORD(v[j]);
+    }
+    sF[0] = sv[0], sB[D - 1] = sv[D - 1];
+    B[D - 1] = F[D - 1];
+#pragma unroll
+    for (int j = D - 2; j >= 1; --j)
+        B[j] = B[j + 1] + F[j], sB[j] = sB[j + 1] ^ sv[j];
+#pragma unroll
+    for (int j = 1; j < D - 1; ++j)
+        F[j] = F[j - 1] + F[j], sF[j] = sF[j - 1] ^ sv[j];
+    v[0] = dm_sat_llr(sB[1], mu, B[1]);
+    v[D - 1] = dm_sat_llr(sF[D - 2], mu, F[D - 2]);
+#pragma unroll
+    for (int j = 1; j < D - 1; ++j)
+        v[j] = dm_sat_llr(sF[j - 1] ^ sB[j + 1], mu, F[j - 1] + B[j + 1]);
+}
+
 template <int D, bool MINSUM>
 __device__ __forceinline__ void cn_core(double (&v)[D])
 {
     if constexpr (!MINSUM && D > 2) // a degree-2 node only swaps its two inputs: the generic code below
     {
-        // sum-product: the recursion is carried in E = e^-|L| (detmath.h, dm_e_combine / dm_efrac / dm_e_to_llr) while
-        // every input is within DM_SHARED_LIMIT; otherwise the direct box-plus below
-        double amax = 0.0;
+        // sum-product: saturated form when it applies; else the recursion is carried in E = e^-|L| (detmath.h,
+        // dm_e_combine / dm_efrac / dm_e_to_llr) while every input is within DM_SHARED_LIMIT; otherwise the direct
+        // box-plus below
+        double amax = 0.0, mu = __builtin_huge_val();
 #pragma unroll
         for (int j = 0; j < D; ++j)
+        {
             amax = __builtin_fmax(amax, __builtin_fabs(v[j]));
+            mu = __builtin_fmin(mu, __builtin_fabs(v[j]));
+        }
+        if (dm_sat_applies(mu, amax))
+        {
+            cn_saturated<D>(v, mu);
+            return;
+        }
         if (amax <= DM_SHARED_LIMIT)
         {
             double ev[D];

@@ -78,63 +78,93 @@ __device__ __forceinline__ void cn_update(double *m, int stride)
 // register; same recursion, same order, same arithmetic as cn_core (E-domain form while every input is within
 // DM_SHARED_LIMIT and the node has at most 64 edges — the limit of the oracle's shared form — else the reference
 // expression term by term).  decoder.cpp:31-44.
+// E-domain form of a wide node (SAT: saturated form, detmath.h): partial results as (sign, fraction n/d of E = e^-|L|), the
+// sign rides in n's sign bit (n > 0); F[j] (inputs 0..j) goes to scr[j] (n) and scr2[j] (d) for 1 <= j <= d-3, the
+// backward partial stays in registers.  Saturated: E' = e^-(|L| - mu), sums instead of fractions (d is not used).
+template <bool SAT>
+__device__ __forceinline__ void cn_wide_eform(double *m, double *scr, double *scr2, int stride, int d, double mu)
+{
+    auto enc = [](uint32_t sw, double e) { return dm_from_bits(dm_bits(e) | (static_cast<uint64_t>(sw & 0x80000000u) << 32)); };
+    auto ex = [&](double v) { return SAT ? dm_sat_e(__builtin_fabs(v), mu) : dm_boxplus_exp(__builtin_fabs(v)); };
+    auto first = [](double a, double b) {
+        if constexpr (SAT)
+            return dm_efrac{a + b, 1.0};
+        else
+            return dm_efrac_first(a, b);
+    };
+    auto step = [](dm_efrac f, double c) {
+        if constexpr (SAT)
+            return dm_efrac{f.n + c, 1.0};
+        else
+            return dm_efrac_step(f, c);
+    };
+    auto llr1 = [&](uint32_t sw, dm_efrac f) { return SAT ? dm_sat_llr(sw, mu, f.n) : dm_e_to_llr(sw, dm_efrac_e(f)); };
+    auto llr2 = [&](uint32_t sw, dm_efrac f, dm_efrac g) {
+        return SAT ? dm_sat_llr(sw, mu, f.n + g.n) : dm_e_to_llr(sw, dm_efrac_e2(f, g));
+    };
+    const double v0 = m[0], v1 = m[stride];
+    const double e0 = ex(v0);
+    dm_efrac F = first(e0, ex(v1));
+    uint32_t sF = DM_SIGN_WORD(v0) ^ DM_SIGN_WORD(v1);
+    scr[stride] = enc(sF, F.n), scr2[stride] = F.d;
+    for (int j = 2; j <= d - 2; ++j)
+    {
+        const double v = m[j * stride];
+        F = step(F, ex(v));
+        sF ^= DM_SIGN_WORD(v);
+        if (j <= d - 3)
+            scr[j * stride] = enc(sF, F.n), scr2[j * stride] = F.d;
+    }
+    const double vl = m[(d - 1) * stride], vl2 = m[(d - 2) * stride];
+    const double el = ex(vl);
+    m[(d - 1) * stride] = llr1(sF, F); // c2v[d-1] = F[d-2]
+    // j = d-2: F[d-3] [+] raw input d-1
+    {
+        const double fn = scr[(d - 3) * stride];
+        dm_efrac f3;
+        f3.n = __builtin_fabs(fn), f3.d = scr2[(d - 3) * stride];
+        m[(d - 2) * stride] = llr1(DM_SIGN_WORD(fn) ^ DM_SIGN_WORD(vl), step(f3, el));
+    }
+    dm_efrac B = first(el, ex(vl2)); // B[d-2]
+    uint32_t sB = DM_SIGN_WORD(vl) ^ DM_SIGN_WORD(vl2);
+    for (int j = d - 3; j >= 2; --j)
+    {
+        const double v = m[j * stride];
+        const double fn = scr[(j - 1) * stride]; // F[j-1], j-1 >= 1: a fraction
+        dm_efrac f;
+        f.n = __builtin_fabs(fn), f.d = scr2[(j - 1) * stride];
+        m[j * stride] = llr2(DM_SIGN_WORD(fn) ^ sB, f, B); // F[j-1] [+] B[j+1]
+        B = step(B, ex(v));                                 // B[j]
+        sB ^= DM_SIGN_WORD(v);
+    }
+    // here B = B[2], sB its sign; j = 1: raw input 0 [+] B[2]; then B[1] = c2v[0]
+    m[stride] = llr1(DM_SIGN_WORD(v0) ^ sB, step(B, e0));
+    B = step(B, ex(v1));
+    sB ^= DM_SIGN_WORD(v1);
+    m[0] = llr1(sB, B);
+}
+
 template <bool MINSUM>
 __device__ __noinline__ void cn_wide(double *m, double *scr, double *scr2, int stride, int d)
 {
-    bool shared = !MINSUM && d <= 64;
-    if (shared)
+    if (!MINSUM && d <= 64)
     {
-        double amax = 0.0;
+        double amax = 0.0, mu = __builtin_huge_val();
         for (int j = 0; j < d; ++j)
+        {
             amax = __builtin_fmax(amax, __builtin_fabs(m[j * stride]));
-        shared = amax <= DM_SHARED_LIMIT;
-    }
-    if (shared)
-    {
-        // partial results as (sign, fraction n/d of E = e^-|L|), detmath.h dm_efrac: the sign rides in n's sign bit (n > 0);
-        // F[j] (inputs 0..j) goes to scr[j] (n) and scr2[j] (d) for 1 <= j <= d-3, the backward partial stays in registers
-        auto enc = [](uint32_t sw, double e) { return dm_from_bits(dm_bits(e) | (static_cast<uint64_t>(sw & 0x80000000u) << 32)); };
-        const double v0 = m[0], v1 = m[stride];
-        const double e0 = dm_boxplus_exp(__builtin_fabs(v0));
-        dm_efrac F = dm_efrac_first(e0, dm_boxplus_exp(__builtin_fabs(v1)));
-        uint32_t sF = DM_SIGN_WORD(v0) ^ DM_SIGN_WORD(v1);
-        scr[stride] = enc(sF, F.n), scr2[stride] = F.d;
-        for (int j = 2; j <= d - 2; ++j)
-        {
-            const double v = m[j * stride];
-            F = dm_efrac_step(F, dm_boxplus_exp(__builtin_fabs(v)));
-            sF ^= DM_SIGN_WORD(v);
-            if (j <= d - 3)
-                scr[j * stride] = enc(sF, F.n), scr2[j * stride] = F.d;
+            mu = __builtin_fmin(mu, __builtin_fabs(m[j * stride]));
         }
-        const double vl = m[(d - 1) * stride], vl2 = m[(d - 2) * stride];
-        const double el = dm_boxplus_exp(__builtin_fabs(vl));
-        m[(d - 1) * stride] = dm_e_to_llr(sF, dm_efrac_e(F)); // c2v[d-1] = F[d-2]
-        // j = d-2: F[d-3] [+] raw input d-1
+        if (dm_sat_applies(mu, amax))
         {
-            const double fn = scr[(d - 3) * stride];
-            dm_efrac f3;
-            f3.n = __builtin_fabs(fn), f3.d = scr2[(d - 3) * stride];
-            m[(d - 2) * stride] = dm_e_to_llr(DM_SIGN_WORD(fn) ^ DM_SIGN_WORD(vl), dm_efrac_e(dm_efrac_step(f3, el)));
+            cn_wide_eform<true>(m, scr, scr2, stride, d, mu);
+            return;
         }
-        dm_efrac B = dm_efrac_first(el, dm_boxplus_exp(__builtin_fabs(vl2))); // B[d-2]
-        uint32_t sB = DM_SIGN_WORD(vl) ^ DM_SIGN_WORD(vl2);
-        for (int j = d - 3; j >= 2; --j)
+        if (amax <= DM_SHARED_LIMIT)
         {
-            const double v = m[j * stride];
-            const double fn = scr[(j - 1) * stride]; // F[j-1], j-1 >= 1: a fraction
-            dm_efrac f;
-            f.n = __builtin_fabs(fn), f.d = scr2[(j - 1) * stride];
-            m[j * stride] = dm_e_to_llr(DM_SIGN_WORD(fn) ^ sB, dm_efrac_e2(f, B)); // F[j-1] [+] B[j+1]
-            B = dm_efrac_step(B, dm_boxplus_exp(__builtin_fabs(v)));                  // B[j]
-            sB ^= DM_SIGN_WORD(v);
+            cn_wide_eform<false>(m, scr, scr2, stride, d, 0.0);
+            return;
         }
-        // here B = B[2], sB its sign; j = 1: raw input 0 [+] B[2]; then B[1] = c2v[0]
-        m[stride] = dm_e_to_llr(DM_SIGN_WORD(v0) ^ sB, dm_efrac_e(dm_efrac_step(B, e0)));
-        B = dm_efrac_step(B, dm_boxplus_exp(__builtin_fabs(v1)));
-        sB ^= DM_SIGN_WORD(v1);
-        m[0] = dm_e_to_llr(sB, dm_efrac_e(B));
-        return;
     }
     double f = m[0];
     scr[0] = f;

@@ -106,8 +106,6 @@ struct DevReg2Plan
     int nt, kc, maxd, nv0, nv1;
     uint32_t neutral, lds_entries;
     const uint32_t *edge_w;
-    const uint64_t *round0_mask;
-    const uint64_t *round1_mask;
     const uint8_t *cn_deg;
     const Reg2VnBlock *vn_blocks;
     const uint32_t *vn_rank;

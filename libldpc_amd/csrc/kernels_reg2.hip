@@ -192,11 +192,9 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
             ew[k][j] = R.edge_w[(k * MAXD + j) * NT + tid];
         }
     }
-    // which of this thread's edges go to the mailbox in round 0 / round 1 (bit k*MAXD+j).  The words are re-read through
-    // an opaque asm in every iteration: otherwise the compiler hoists all 2*KC*MAXD exec masks out of the loop into
-    // SGPR pairs and spills most of them
-    uint32_t rm0l = static_cast<uint32_t>(R.round0_mask[tid]), rm0h = static_cast<uint32_t>(R.round0_mask[tid] >> 32);
-    uint32_t rm1l = static_cast<uint32_t>(R.round1_mask[tid]), rm1h = static_cast<uint32_t>(R.round1_mask[tid] >> 32);
+    // every thread writes all its columns in both mailbox rounds; the ones that do not belong to the round (or hold no
+    // edge) land in the trash entry (plan.hpp, edge_w): no execution masks, no branches
+    const uint32_t trash = kReg2TrashEntry * 8u;
     __syncthreads();
 
     double *out_llr = WANT_LLR ? a.llr_out + frame * nc : nullptr;
@@ -217,10 +215,19 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
     for (;;)
     {
         // (the same for the two address fields of the packed edge words: hoisted, they would cost 2*KC*MAXD registers)
-        uint32_t gather_mask = 0x3FFF8u, scatter_shift = 15u, scatter_mask = 0x1FFF8u;
+        uint32_t gather_mask = 0x3FFF8u, scatter_mask = 0x7FFF8u;
         const Reg2VnBlock *vn_blocks = R.vn_blocks;
-        asm volatile("" : "+v"(rm0l), "+v"(rm0h), "+v"(rm1l), "+v"(rm1h), "+v"(gather_mask), "+v"(scatter_shift), "+v"(scatter_mask),
-                     "+s"(vn_blocks));
+        asm volatile("" : "+s"(gather_mask), "+s"(scatter_mask), "+s"(vn_blocks));
+        auto scatter = [&](auto round) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+#pragma unroll
+                for (int j = 0; j < MAXD; ++j)
+                {
+                    const uint32_t at = (__builtin_amdgcn_alignbit(ew[k][j], ew[k][j], 15) & scatter_mask) - decltype(round)::value * 0x20000u;
+                    *lds_abs<double>(at < trash ? at : trash) = m[k][j];
+                }
+        };
         // ---- gather: v2c of every owned edge from its VN's total; syndrome of the decisions in the totals ----
         uint32_t par = 0;
 #pragma unroll
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
             for (int j = 0; j < MAXD; ++j)
             {
                 // (no test on the node's degree here: columns without an edge gather the neutral entry, +1.0, and stay
-                // what they are; straight-line code lets all the loads of a thread be in flight together)
+                // what they are; straight-line code lets all the loads of a check node be in flight together)
                 const double t = *lds_abs<const double>(ew[k][j] & gather_mask);
                 if constexpr (RATIO)
                 {
@@ -283,14 +290,39 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
         }
         // ---- CN pass (decoder.cpp:25-45), entirely in registers; c2v of round-0 edges -> mailbox ----
         [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+#ifdef REG2_UCN
+#ifdef REG2_CNLOOP
+#pragma clang loop unroll(disable)
+            for (int it = 0; it < KC; ++it)
+            {
+                if constexpr (RATIO)
+                    cn_ratio<MAXD>(m[0]);
+                else
+                    cn_core<MAXD, MINSUM>(m[0]);
+#pragma unroll
+                for (int j = 0; j < MAXD; ++j)
+                {
+                    const double t = m[0][j];
+#pragma unroll
+                    for (int k = 0; k + 1 < KC; ++k)
+                        m[k][j] = m[k + 1][j];
+                    m[KC - 1][j] = t;
+                }
+            }
+#else
+            (([&] {
+                 if constexpr (RATIO)
+                     cn_ratio<MAXD>(m[Ks]);
+                 else
+                     cn_core<MAXD, MINSUM>(m[Ks]);
+             }()),
+             ...);
+#endif
+#else
             ((deg[Ks] >= 2 ? cn_regs2<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks]) : void()), ...);
+#endif
         }(std::make_integer_sequence<int, KC>{});
-#pragma unroll
-        for (int k = 0; k < KC; ++k)
-#pragma unroll
-            for (int j = 0; j < MAXD; ++j)
-                if ((k * MAXD + j < 32 ? rm0l : rm0h) & (1u << ((k * MAXD + j) & 31)))
-                    *lds_abs<double>((ew[k][j] >> scatter_shift) & scatter_mask) = m[k][j];
+        scatter(std::integral_constant<uint32_t, 0>{});
         REG2_TICK(2)
         __syncthreads();
         REG2_TICK(3)
@@ -355,12 +387,7 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
         REG2_TICK(4)
         __syncthreads();
         REG2_TICK(5)
-#pragma unroll
-        for (int k = 0; k < KC; ++k)
-#pragma unroll
-            for (int j = 0; j < MAXD; ++j)
-                if ((k * MAXD + j < 32 ? rm1l : rm1h) & (1u << ((k * MAXD + j) & 31)))
-                    *lds_abs<double>((ew[k][j] >> scatter_shift) & scatter_mask) = m[k][j];
+        scatter(std::integral_constant<uint32_t, 1>{});
         REG2_TICK(6)
         __syncthreads();
         REG2_TICK(7)

@@ -290,12 +290,14 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
         }
     r.e_max = (std::max(e0, e1) + 31u) & ~31u;
     const uint32_t n_tot0 = static_cast<uint32_t>(rb[0].size()) * kWaveSize;
-    r.neutral = r.e_max + n_tot0;
+    // the trash entry sits at byte 0x20000 exactly (plan.hpp): the round-0 totals go below it when they fit there
+    const uint32_t tot_base = r.e_max + n_tot0 <= kReg2TrashEntry ? r.e_max : kReg2TrashEntry + kWaveSize;
+    r.neutral = std::max(tot_base + n_tot0, kReg2TrashEntry + 1);
     r.lds_entries = r.neutral + 2;
-    if (r.e_max > 16383u || static_cast<size_t>(r.lds_entries) * 8 + 64 > 160 * 1024)
+    if (r.e_max > kReg2TrashEntry || static_cast<size_t>(r.lds_entries) * 8 + 64 > 160 * 1024)
         return r;
     for (Reg2VnBlock *o : placed[0])
-        o->tot_off += r.e_max;
+        o->tot_off += tot_base;
 
     // ---- which variable node sits in which (block, lane) ----
     // Every offset above is a multiple of 32 entries plus the lane (full blocks), so the LDS bank of a node's total
@@ -304,7 +306,9 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
     // The check-node side reads and writes in fixed lane groups — the j-th edges of 32 (16) neighbouring check nodes —
     // so nodes are placed greedily where their lane collides least with the nodes already placed in the same groups
     // (same degree class only: blocks are uniform in degree).  Natural order costs 3.5 LDS cycles per gather group
-    // and 2.2 per scatter group on the (3,6) n=8192 code; this placement 2.0 and 1.15.
+    // and 2.2 per scatter group on the (3,6) n=8192 code; this placement 2.0 and 1.15 (tools/reg2_plan_stats.cpp).  In the
+    // round an edge's node does not belong to, the edge's owner writes the trash entry — one address for all lanes,
+    // one more access to bank 0 of the group.
     struct Slot { uint32_t rd, q, lane; };
     const int max_deg = plan.max_vn_degree;
     std::vector<std::vector<std::vector<Slot>>> free_slots(max_deg + 1, std::vector<std::vector<Slot>>(64)); // [degree][rd*32 + colour]
@@ -337,6 +341,8 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
         }
     }
     std::vector<uint16_t> g_cnt(static_cast<size_t>(n_gg) * 32, 0), s_cnt(static_cast<size_t>(n_sg) * 2 * 16, 0);
+    for (size_t g = 0; g < s_cnt.size(); g += 16)
+        s_cnt[g + kReg2TrashEntry % 16] = 1; // the trash entry
     std::vector<uint32_t> order(plan.nc);
     std::iota(order.begin(), order.end(), 0u);
     uint64_t rng = 0x9E3779B97F4A7C15ull; // fixed seed: the plan is a pure function of the code
@@ -395,8 +401,7 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
             edge_round[e] = static_cast<uint8_t>(sl.rd);
         }
     }
-    r.edge_w.assign(static_cast<size_t>(kc) * maxd * NT, r.neutral << 3);
-    r.round0_mask.assign(NT, 0), r.round1_mask.assign(NT, 0);
+    r.edge_w.assign(static_cast<size_t>(kc) * maxd * NT, (r.neutral << 3) | 2u);
     r.cn_deg.assign(static_cast<size_t>(kc) * W, 0), r.cn_cnt.assign(static_cast<size_t>(kc) * W, 0);
     int rank = 0; // CN rank in the Plan's order (cn_rank_row), block by block
     for (int bi = 0; bi < n_cb; ++bi)
@@ -412,8 +417,7 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
             for (int j = 0; j < cb.degree; ++j)
             {
                 const int e = H.redge[H.rptr[row] + j], s = k * maxd + j;
-                r.edge_w[static_cast<size_t>(s) * NT + tid] = (edge_gather[e] << 3) | (edge_scatter[e] << 18);
-                (edge_round[e] ? r.round1_mask : r.round0_mask)[tid] |= 1ull << s;
+                r.edge_w[static_cast<size_t>(s) * NT + tid] = (edge_gather[e] << 3) | (edge_scatter[e] << 18) | edge_round[e];
             }
         }
     }

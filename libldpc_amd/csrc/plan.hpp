@@ -118,9 +118,15 @@ struct RegPlan
 //                                 p0_off + lane (position 0) and prest_off + (p-1)*count + lane (positions >= 1)
 //   entries [e_max, e_max + n0)   totals of the round-0 variable nodes (round-1 totals are written in place, over
 //                                 position 0 of their column, which nothing overwrites before the gather)
+//   entry   16384                 trash, at byte 0x20000 exactly: every thread writes all its register columns in
+//                                 both rounds, and the address arithmetic sends the columns whose node belongs to
+//                                 the other round (or that hold no edge) here (edge_w below)
 //   entry   neutral               +1.0: what register columns without an edge gather
+//   (when the round-0 totals do not fit below the trash entries they follow them)
 //
 // Variable-node blocks are dealt to (round, i, wave): wave w handles blocks [(round, i, w)] for i < nv[round].
+
+constexpr uint32_t kReg2TrashEntry = 16384; // byte 0x20000
 
 struct Reg2VnBlock
 {
@@ -136,11 +142,12 @@ struct Reg2Plan
     bool ok = false;
     int nt = 0, kc = 0, maxd = 0, nv0 = 0, nv1 = 0;
     uint32_t e_max = 0, neutral = 0, lds_entries = 0;
-    // [(k*maxd + j)*nt + tid]: bits 0..17 = byte address the edge's VN total is gathered from,
-    // bits 18..31 = mailbox entry the edge's c2v message is scattered to
+    // [(k*maxd + j)*nt + tid]: bits 3..17 = byte address the edge's VN total is gathered from, bits 18..31 = mailbox
+    // entry the edge's c2v message is scattered to, bit 0 = the round of the edge's node, bit 1 = no edge.  Rotated
+    // right by 15 and masked with 0x7FFF8 the word is the scatter byte address plus 0x20000 (round 1) or 0x40000 (no
+    // edge): round r subtracts r * 0x20000 and takes the unsigned minimum with the trash address 0x20000, which leaves
+    // the addresses of its own round alone and sends everything else to trash.
     std::vector<uint32_t> edge_w;
-    std::vector<uint64_t> round0_mask; // [tid] bit k*maxd+j: the edge exists and its VN is a round-0 node
-    std::vector<uint64_t> round1_mask; // [tid] ... a round-1 node
     std::vector<uint8_t> cn_deg;       // [k*(nt/64) + wave] degree of that CN block (0 = none)
     std::vector<uint8_t> cn_cnt;       // [k*(nt/64) + wave] check nodes in the block
     std::vector<Reg2VnBlock> vn_blocks; // [(i*(nt/64) + wave)], i < nv0 + nv1 (i < nv0: round 0)

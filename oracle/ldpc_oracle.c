@@ -367,8 +367,9 @@ static void dec_free(dec_t *d)
 
 /*
  * ORC_MATH_DET only: the forward/backward recursion (decoder.cpp:31-44) carried in E = e^-|L| (detmath.h,
- * dm_e_combine / dm_e_to_llr) — the arithmetic the HIP kernel runs.  Returns 0 (nothing done) when an input
- * exceeds DM_SHARED_LIMIT; the caller then evaluates this node with dm_boxplus, as the kernel does.
+ * dm_e_combine / dm_e_to_llr) — the arithmetic the HIP kernel runs — or, when every input is large and they lie
+ * close together, the saturated form (detmath.h, dm_sat_*).  Returns 0 (nothing done) when neither applies (an input
+ * exceeds DM_SHARED_LIMIT); the caller then evaluates this node with dm_boxplus, as the kernel does.
  * F[cw-1] and B[0], which the reference computes and never reads, are not evaluated.
  */
 static int cn_update_det_shared(dec_t *d, const int *cn, int cw)
@@ -378,12 +379,37 @@ static int cn_update_det_shared(dec_t *d, const int *cn, int cw)
     uint32_t sv[MAXD], sF[MAXD], sB[MAXD];
     if (cw > MAXD || cw < 3) /* a degree-2 node only swaps its inputs: generic path */
         return 0;
+    double amax = 0.0, mu = HUGE_VAL;
     for (int j = 0; j < cw; ++j)
     {
         v[j] = d->v2c[cn[j]];
+        amax = fmax(amax, fabs(v[j]));
+        mu = fmin(mu, fabs(v[j]));
+    }
+    if (dm_sat_applies(mu, amax))
+    {
+        /* saturated form (detmath.h): sums of e^-(|v| - mu); F[j] = inputs 0..j, B[j] = inputs j..cw-1 */
+        double Fs[MAXD], Bs[MAXD];
+        for (int j = 0; j < cw; ++j)
+        {
+            Fs[j] = dm_sat_e(fabs(v[j]), mu);
+            sv[j] = DM_SIGN_WORD(v[j]);
+        }
+        sF[0] = sv[0], sB[cw - 1] = sv[cw - 1];
+        Bs[cw - 1] = Fs[cw - 1];
+        for (int j = cw - 2; j >= 1; --j)
+            Bs[j] = Bs[j + 1] + Fs[j], sB[j] = sB[j + 1] ^ sv[j];
+        for (int j = 1; j < cw - 1; ++j)
+            Fs[j] = Fs[j - 1] + Fs[j], sF[j] = sF[j - 1] ^ sv[j];
+        d->c2v[cn[0]] = dm_sat_llr(sB[1], mu, Bs[1]);
+        d->c2v[cn[cw - 1]] = dm_sat_llr(sF[cw - 2], mu, Fs[cw - 2]);
+        for (int j = 1; j < cw - 1; ++j)
+            d->c2v[cn[j]] = dm_sat_llr(sF[j - 1] ^ sB[j + 1], mu, Fs[j - 1] + Bs[j + 1]);
+        return 1;
+    }
+    for (int j = 0; j < cw; ++j)
         if (!(fabs(v[j]) <= DM_SHARED_LIMIT))
             return 0;
-    }
     for (int j = 0; j < cw; ++j)
     {
         ev[j] = dm_boxplus_exp(fabs(v[j]));

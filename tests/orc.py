@@ -250,6 +250,17 @@ def math_points(fn, n, seed):
     if fn == "boxplus":
         a = mix([rng.normal(0, 10, k), rng.uniform(-50, 50, k), rng.uniform(-700, 700, k), rng.normal(0, 0.01, k), edge])
         b = mix([rng.normal(0, 10, k), rng.uniform(-50, 50, k), rng.uniform(-700, 700, k), a[:k] * rng.choice([-1, 1], k), edge[::-1]])
+        # saturated operands (the device's short cut, device_math.hpp box_jacobian): magnitudes up to 1e15, gaps on both
+        # sides of 37, signed zeros and infinities against large values
+        q = max(n // 8, 8)
+        big = np.ldexp(rng.uniform(0.5, 1, q), rng.integers(-30, 50, q)) * rng.choice([-1, 1], q)
+        gap = np.concatenate([rng.uniform(36.5, 37.5, q // 2), np.ldexp(rng.uniform(0.5, 1, q - q // 2), rng.integers(-20, 45, q - q // 2))])
+        other = (np.abs(big) + gap) * rng.choice([-1, 1], q)
+        special_a = np.array([0.0, -0.0, 0.0, -0.0, np.inf, -np.inf, 7.0, 1e300, -1e300, 37.0, -37.0, 1e-310, 50.0, 0.0])
+        special_b = np.array([40.0, 40.0, -1e9, np.inf, 5.0, -1e9, np.inf, -1e300, 1.0, 0.0, -0.0, -80.0, 13.0, 37.0])
+        a[:q], b[:q] = big, other
+        a[q:2 * q], b[q:2 * q] = other, big
+        a[2 * q:2 * q + special_a.size], b[2 * q:2 * q + special_a.size] = special_a, special_b
         return a, b
     if fn == "ratio_div":
         a = np.ldexp(rng.uniform(0.5, 1, n), rng.integers(-499, 500, n))
@@ -280,4 +291,13 @@ def math_points(fn, n, seed):
         return np.exp(L), None
     L = np.concatenate([rng.normal(0, 10, (n // 2, d)), rng.uniform(-100, 100, (n - n // 2 - 2, d)),
                         np.full((1, d), 600.0), np.zeros((1, d))])
+    # saturated nodes (detmath.h, dm_sat_*): a large common magnitude plus offsets of the order of channel LLRs, the two
+    # edges of the rule (smallest input around 40, spread around 600), and nodes that must take the box-plus chain
+    q = n // 4
+    big = 10.0 ** rng.uniform(1.5, 13, (q, 1)) + rng.normal(0, 20, (q, d))
+    L[:q] = np.abs(big) * rng.choice([-1, 1], (q, d))
+    e = q // 4
+    L[q:q + e] = (rng.uniform(39.5, 40.5, (e, 1)) + rng.exponential(30, (e, d))) * rng.choice([-1, 1], (e, d))
+    L[q + e:q + 2 * e] = (rng.uniform(50, 1e4, (e, 1)) + rng.uniform(0, 1, (e, d)) * rng.uniform(590, 610, (e, 1))) * rng.choice([-1, 1], (e, d))
+    L[q + 2 * e:q + 3 * e] = rng.uniform(-2000, 2000, (e, d))
     return L, None

@@ -103,8 +103,8 @@ const char *ldpc_hip_last_error(void);
 /* parse the code (host only; the GPU is touched lazily by the first decode). NULL on error. */
 ldpc_hip_ctx *ldpc_hip_create(const char *pcFile, const char *genFile, int device);
 void ldpc_hip_destroy(ldpc_hip_ctx *ctx);
-/* info[0..9] = nc, mc, nnz, nct, mct, kct, kc, max_degree, residency (0 memory, 1 LDS, 2 registers),
-   lds_bytes_per_frame */
+/* info[0..9] = nc, mc, nnz, nct, mct, kct, kc, max_degree, residency (0 memory, 1 LDS, 2 registers with a message
+   mailbox, 3 registers with variable-node totals returned), lds_bytes_per_frame */
 void ldpc_hip_code_info(const ldpc_hip_ctx *ctx, int64_t info[10]);
 /* the text block the reference CLI prints for a code (ldpc.cpp:111-130); owned by the context */
 const char *ldpc_hip_describe(ldpc_hip_ctx *ctx);

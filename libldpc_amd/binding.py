@@ -180,7 +180,8 @@ class HipDecoder:
         (self.nc, self.mc, self.nnz, self.nct, self.mct, self.kct, self.kc, self.max_degree, lds,
          self.lds_bytes) = list(info)
         self.lds_resident = lds == 1
-        self.residency = {0: "memory", 1: "lds", 2: "registers"}[int(lds)]
+        self.residency = {0: "memory", 1: "lds", 2: "registers", 3: "registers"}[int(lds)]
+        self.register_form = {2: "messages", 3: "totals"}.get(int(lds))  # which register-resident kernel
 
     def close(self):
         if getattr(self, "ctx", None):

@@ -239,8 +239,10 @@ void ldpc_hip_code_info(const ldpc_hip_ctx *ctx, int64_t info[10])
     info[0] = c.nc(), info[1] = c.mc(), info[2] = c.nnz(), info[3] = c.nct(), info[4] = c.mct();
     info[5] = c.kct(), info[6] = c.kc(), info[7] = c.max_degree, info[8] = p.lds_ok;
     info[9] = static_cast<int64_t>(p.lds_bytes);
-    if (!p.lds_ok && ctx->eng->reg_plan().ok)
-        info[8] = 2; // register-resident decoder
+    if (!p.lds_ok && ctx->eng->reg2_plan().ok)
+        info[8] = 3; // register-resident decoder, totals form (kernels_reg2.hip)
+    else if (!p.lds_ok && ctx->eng->reg_plan().ok)
+        info[8] = 2; // register-resident decoder, messages form (kernels_reg.hip)
 }
 
 const char *ldpc_hip_describe(ldpc_hip_ctx *ctx)

@@ -488,6 +488,7 @@ void Engine::upload_plan()
         const Reg2Plan &r = reg2_plan_;
         dev_reg2_.nt = r.nt, dev_reg2_.kc = r.kc, dev_reg2_.maxd = r.maxd, dev_reg2_.nv0 = r.nv0, dev_reg2_.nv1 = r.nv1;
         dev_reg2_.neutral = r.neutral, dev_reg2_.lds_entries = r.lds_entries;
+        dev_reg2_.uniform_cn = r.uniform_cn ? 1 : 0;
         dev_reg2_.edge_w = static_cast<const uint32_t *>(up(r.edge_w.data(), r.edge_w.size() * 4));
         dev_reg2_.cn_deg = static_cast<const uint8_t *>(up(r.cn_deg.data(), r.cn_deg.size()));
         dev_reg2_.vn_blocks = static_cast<const Reg2VnBlock *>(up(r.vn_blocks.data(), r.vn_blocks.size() * sizeof(Reg2VnBlock)));

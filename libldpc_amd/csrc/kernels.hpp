@@ -105,6 +105,7 @@ struct DevReg2Plan
 {
     int nt, kc, maxd, nv0, nv1;
     uint32_t neutral, lds_entries;
+    int uniform_cn; // every check-node block has maxd edges
     const uint32_t *edge_w;
     const uint8_t *cn_deg;
     const Reg2VnBlock *vn_blocks;

@@ -106,7 +106,9 @@ __device__ __forceinline__ Reg2VnBlock load_vn_block(const Reg2VnBlock *table, u
 // RATIO: the likelihood-ratio form of the sum-product iteration (detmath.h): c2v messages are lambda = e^-L, the
 // returned total is rho(total) = 1 / (lambda(L_ch) * prod lambda(c2v)) with the hard decision in its sign bit, the
 // owner's v2c is rho(total) * lambda(c2v_e); frames that leave the representable box go to a.redo_list.
-template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, int NV0, int NV1, bool RATIO, bool REDO>
+// UCN: every check-node block of the plan has exactly MAXD edges (a regular code): no switch over the degree, a third of
+// the code.
+template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, int NV0, int NV1, bool RATIO, bool REDO, bool UCN>
 __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, const DevReg2Plan R)
 {
     static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
@@ -290,37 +292,18 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
         }
         // ---- CN pass (decoder.cpp:25-45), entirely in registers; c2v of round-0 edges -> mailbox ----
         [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
-#ifdef REG2_UCN
-#ifdef REG2_CNLOOP
-#pragma clang loop unroll(disable)
-            for (int it = 0; it < KC; ++it)
-            {
-                if constexpr (RATIO)
-                    cn_ratio<MAXD>(m[0]);
-                else
-                    cn_core<MAXD, MINSUM>(m[0]);
-#pragma unroll
-                for (int j = 0; j < MAXD; ++j)
-                {
-                    const double t = m[0][j];
-#pragma unroll
-                    for (int k = 0; k + 1 < KC; ++k)
-                        m[k][j] = m[k + 1][j];
-                    m[KC - 1][j] = t;
-                }
-            }
-#else
             (([&] {
-                 if constexpr (RATIO)
+                 if constexpr (!UCN)
+                 {
+                     if (deg[Ks] >= 2)
+                         cn_regs2<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks]);
+                 }
+                 else if constexpr (RATIO)
                      cn_ratio<MAXD>(m[Ks]);
                  else
                      cn_core<MAXD, MINSUM>(m[Ks]);
              }()),
              ...);
-#endif
-#else
-            ((deg[Ks] >= 2 ? cn_regs2<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks]) : void()), ...);
-#endif
         }(std::make_integer_sequence<int, KC>{});
         scatter(std::integral_constant<uint32_t, 0>{});
         REG2_TICK(2)
@@ -479,14 +462,24 @@ int launch_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, void *s
     if (redo && (min_sum || !a.redo_list_in))
         return hipErrorInvalidValue;
     void (*k)(const DecodeArgs, const DevReg2Plan) = nullptr;
-    if (min_sum)
-        k = want_llr ? decode_reg2_kernel<true, true, NT, KC, MAXD, NV0, NV1, false, false> : decode_reg2_kernel<true, false, NT, KC, MAXD, NV0, NV1, false, false>;
-    else if (ratio)
-        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true, false> : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true, false>;
-    else if (redo)
-        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, true> : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, true>;
+    auto pick = [&]<bool UCN>(std::bool_constant<UCN>) {
+        if (min_sum)
+            k = want_llr ? decode_reg2_kernel<true, true, NT, KC, MAXD, NV0, NV1, false, false, UCN>
+                         : decode_reg2_kernel<true, false, NT, KC, MAXD, NV0, NV1, false, false, UCN>;
+        else if (ratio)
+            k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true, false, UCN>
+                         : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true, false, UCN>;
+        else if (redo)
+            k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, true, UCN>
+                         : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, true, UCN>;
+        else
+            k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, false, UCN>
+                         : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, false, UCN>;
+    };
+    if (r.uniform_cn)
+        pick(std::true_type{});
     else
-        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, false> : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, false>;
+        pick(std::false_type{});
     const unsigned grid = redo ? static_cast<unsigned>(std::min<uint64_t>(a.n_frames, 512)) : static_cast<unsigned>(a.n_frames);
     const uint32_t lds = r.lds_entries * 8u + 16u;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,

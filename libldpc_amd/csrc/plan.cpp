@@ -421,6 +421,7 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
             }
         }
     }
+    r.uniform_cn = std::all_of(r.cn_deg.begin(), r.cn_deg.end(), [&](uint8_t d) { return d == maxd; });
     r.ok = true;
     return r;
 }

@@ -49,6 +49,48 @@ CASES = [
 ]
 
 
+def make_code_by_degrees(path, vn_degs, cn_degs, rng):
+    """Random graph with prescribed column AND row degrees (socket matching, duplicate edges repaired by swaps)."""
+    assert sum(vn_degs) == sum(cn_degs)
+    cols = np.repeat(np.arange(len(vn_degs)), vn_degs)
+    rows = np.repeat(np.arange(len(cn_degs)), cn_degs)
+    rng.shuffle(cols)
+    for _ in range(200):
+        key = rows.astype(np.int64) * len(vn_degs) + cols
+        _, first = np.unique(key, return_index=True)
+        dup = np.setdiff1d(np.arange(key.size), first)
+        if dup.size == 0:
+            break
+        other = rng.integers(0, key.size, dup.size)
+        cols[dup], cols[other] = cols[other].copy(), cols[dup].copy()
+    else:
+        raise AssertionError("could not repair duplicate edges")
+    order = np.lexsort((cols, rows))
+    open(path, "w").write("\n".join(f"{r} {c}" for r, c in zip(rows[order], cols[order])))
+    return path
+
+
+def test_irregular_code_totals_form(tmp_path):
+    """The second register-resident kernel (totals form, kernels_reg2.hip) on a code that is NOT regular: check nodes
+    of degree 5 and 6 (the generic instantiation with its switch over the degree, partly filled blocks), variable nodes
+    of degree 2 and 3; 20800 messages = 166 KB, beyond LDS.  Bit for bit against the det oracle, sum-product with and
+    without early termination (ratio form, second pass, LLR domain with the saturated form) and min-sum."""
+    import libldpc_amd
+    rng = np.random.default_rng(11)
+    path = make_code_by_degrees(str(tmp_path / "irr.txt"), [2] * 3008 + [3] * 4928, [5] * 560 + [6] * 3000, rng)
+    code = orc.Code(path)
+    d = libldpc_amd.HipDecoder(path)
+    assert (d.nc, d.mc, d.nnz) == (7936, 3560, 20800) == (code.nc, code.mc, code.nnz)
+    assert d.residency == "registers" and d.register_form == "totals"
+    for x, ms, early, iters in ((3.0, False, True, 30), (2.2, False, True, 12), (3.0, False, False, 40), (2.6, True, True, 20)):
+        d.stream_begin("AWGN", 5, x)
+        r = d.stream_decode(6, early_term=early, iterations=iters, decoding="BP_MS" if ms else "BP", want=OUT)
+        o = code.run_frames("AWGN", x, seed=5, skip=0, count=6, min_sum=ms, early_term=early, iters=iters, math=orc.MATH_DET)
+        for k in OUT:
+            assert np.array_equal(r[k], o[k].astype(r[k].dtype)), (x, ms, early, k)
+    assert 0 < r["iters"].min()
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_random_code_bit_exact(case, tmp_path):
     import libldpc_amd

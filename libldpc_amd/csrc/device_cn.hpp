@@ -162,16 +162,12 @@ __device__ __forceinline__ void cn_ratio(double (&v)[D])
     {
         // D >= 5: partial results stay undivided fractions (detmath.h, dm_frac): D divisions, not 3(D-2).
         // F[j] = inputs 0..j, B[j] = inputs j..D-1; a partial over an odd number >= 3 of inputs is rescaled.
-        dm_frac F[D], B[D];
-        F[1] = dm_frac_first(v[0], v[1]);
+        // Order of evaluation: the backward partials first, then one forward sweep that emits every output as soon as
+        // its two partials exist and overwrites the input it no longer needs — D-3 stored fractions and one running
+        // one instead of 2(D-3) fractions plus D pending outputs (the register-resident kernels have no registers to
+        // spare; the fences keep the scheduler from interleaving the steps again).  Same operations, same values.
+        dm_frac B[D];
         B[D - 2] = dm_frac_first(v[D - 1], v[D - 2]);
-#pragma unroll
-        for (int j = 2; j <= D - 3; ++j)
-        {
-            F[j] = dm_frac_step(F[j - 1], v[j]);
-            if ((j + 1) % 2 == 1)
-                F[j] = dm_frac_norm(F[j]);
-        }
 #pragma unroll
         for (int j = D - 3; j >= 2; --j)
         {
@@ -179,17 +175,27 @@ __device__ __forceinline__ void cn_ratio(double (&v)[D])
             if ((D - j) % 2 == 1)
                 B[j] = dm_frac_norm(B[j]);
         }
-        double o[D];
-        o[0] = dm_ratio_lambda_frac(B[2].n, B[2].d, v[1]);             // B[1] = B[2] [+] v[1]
-        o[1] = dm_ratio_lambda_frac(B[2].n, B[2].d, v[0]);             // F[0] [+] B[2]
-        o[D - 2] = dm_ratio_lambda_frac(F[D - 3].n, F[D - 3].d, v[D - 1]); // F[D-3] [+] B[D-1]
-        o[D - 1] = dm_ratio_lambda_frac(F[D - 3].n, F[D - 3].d, v[D - 2]); // F[D-2] = F[D-3] [+] v[D-2]
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const double o0 = dm_ratio_lambda_frac(B[2].n, B[2].d, v[1]); // B[1] = B[2] [+] v[1]
+            const double o1 = dm_ratio_lambda_frac(B[2].n, B[2].d, v[0]); // F[0] [+] B[2]
+            dm_frac F = dm_frac_first(v[0], v[1]);                        // F[1]
+            v[0] = o0, v[1] = o1;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 2; j <= D - 3; ++j)
-            o[j] = dm_frac_lambda2(F[j - 1], B[j + 1]);
-#pragma unroll
-        for (int j = 0; j < D; ++j)
-            v[j] = o[j];
+            for (int j = 2; j <= D - 3; ++j)
+            {
+                const double o = dm_frac_lambda2(F, B[j + 1]); // F[j-1] [+] B[j+1]
+                F = dm_frac_step(F, v[j]);                     // F[j]
+                if ((j + 1) % 2 == 1)
+                    F = dm_frac_norm(F);
+                v[j] = o;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const double oa = dm_ratio_lambda_frac(F.n, F.d, v[D - 1]); // F[D-3] [+] B[D-1]
+            const double ob = dm_ratio_lambda_frac(F.n, F.d, v[D - 2]); // F[D-2] = F[D-3] [+] v[D-2]
+            v[D - 2] = oa, v[D - 1] = ob;
+        }
     }
 }
 

@@ -489,6 +489,8 @@ void Engine::upload_plan()
         dev_reg2_.nt = r.nt, dev_reg2_.kc = r.kc, dev_reg2_.maxd = r.maxd, dev_reg2_.nv0 = r.nv0, dev_reg2_.nv1 = r.nv1;
         dev_reg2_.neutral = r.neutral, dev_reg2_.lds_entries = r.lds_entries;
         dev_reg2_.uniform_cn = r.uniform_cn ? 1 : 0;
+        dev_reg2_.uniform_vn = r.uniform_vn ? 1 : 0;
+        std::memcpy(dev_reg2_.vn_affine, r.vn_affine, sizeof r.vn_affine);
         dev_reg2_.edge_w = static_cast<const uint32_t *>(up(r.edge_w.data(), r.edge_w.size() * 4));
         dev_reg2_.cn_deg = static_cast<const uint8_t *>(up(r.cn_deg.data(), r.cn_deg.size()));
         dev_reg2_.vn_blocks = static_cast<const Reg2VnBlock *>(up(r.vn_blocks.data(), r.vn_blocks.size() * sizeof(Reg2VnBlock)));
@@ -584,7 +586,11 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
             a.ws_llr = static_cast<double *>(ws_llr_.reserve(8 * n * nc));
             a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nc));
             if (reg2_plan_.ok)
+            {
+                // channel terms of the variable nodes, one per (block slot, thread): kernels_reg2.hip
+                a.ws_scr = static_cast<double *>(ws_scr_.reserve(8 * n * static_cast<uint64_t>(reg2_plan_.nv0 + reg2_plan_.nv1) * reg2_plan_.nt));
                 check(launch_decode_reg2(a, dev_reg2_, p.min_sum, s), "decode (register-resident, totals form)");
+            }
             else
                 check(launch_decode_reg(a, dev_reg_, p.min_sum, s), "decode (register-resident)");
         }

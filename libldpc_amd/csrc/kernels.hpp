@@ -71,7 +71,8 @@ struct DecodeArgs
     double *ws_msg;  // [n_frames][nnz]
     double *ws_llr;  // [n_frames][nc]
     uint8_t *ws_hb;  // [n_frames][nnz]
-    double *ws_scr;  // [n_frames][2 nnz] scratch of check nodes wider than 16 (nullptr when the code has none)
+    double *ws_scr;  // [n_frames][2 nnz] scratch of check nodes wider than 16 (nullptr when the code has none);
+                     // totals-form register kernel: [n_frames][(nv0 + nv1) * nt] channel terms of the variable nodes
     // sum-product in likelihood-ratio form (detmath.h): when redo_list is set the launch runs that form and
     // appends the frames it could not finish to redo_list[atomicAdd(redo_count)]; a launch with redo_list_in /
     // redo_count_in set decodes exactly those frames (block b takes frame redo_list_in[b], b < *redo_count_in)
@@ -106,6 +107,10 @@ struct DevReg2Plan
     int nt, kc, maxd, nv0, nv1;
     uint32_t neutral, lds_entries;
     int uniform_cn; // every check-node block has maxd edges
+    int uniform_vn; // every variable-node block is full, of degree 3, at the affine offsets below
+    // round r: column position 0 of block q = i * (nt/64) + wave at entry vn_affine[r][0] + vn_affine[r][1] * q (+ lane),
+    // positions 1.. at [2] + [3] * q (+ 64 per position), the total at [4] + [5] * q
+    uint32_t vn_affine[2][6];
     const uint32_t *edge_w;
     const uint8_t *cn_deg;
     const Reg2VnBlock *vn_blocks;

@@ -31,6 +31,7 @@
 #include "device_math.hpp"
 #include "kernels.hpp"
 
+
 namespace ldpc_amd
 {
 
@@ -107,10 +108,13 @@ __device__ __forceinline__ Reg2VnBlock load_vn_block(const Reg2VnBlock *table, u
 // returned total is rho(total) = 1 / (lambda(L_ch) * prod lambda(c2v)) with the hard decision in its sign bit, the
 // owner's v2c is rho(total) * lambda(c2v_e); frames that leave the representable box go to a.redo_list.
 // UCN: every check-node block of the plan has exactly MAXD edges (a regular code): no switch over the degree, a third of
-// the code.
-template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, int NV0, int NV1, bool RATIO, bool REDO, bool UCN>
+// the code.  UVN: every variable-node block is full and of degree 3 with columns, rests and totals at affine offsets
+// (DevReg2Plan::vn_affine): a round is straight-line code — channel terms fetched before the barrier that opens the
+// round, all its mailbox reads in flight together, the divisions of its blocks interleaved.
+template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, int NV0, int NV1, bool RATIO, bool REDO, bool UCN, bool UVN>
 __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, const DevReg2Plan R)
 {
+    static_assert(NV0 % 2 == 0 && NV1 % 2 == 0, "variable-node rounds go two blocks at a time");
     static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
     static_assert(!(RATIO && REDO), "the second pass runs the LLR-domain form");
     constexpr int W = NT / 64, NV = NV0 + NV1;
@@ -154,13 +158,16 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
     // ---- variable-node side: input LLRs (RATIO: as lambda = e^-L) into registers, first totals into LDS ----
     // v2c initialisation (decoder.cpp:16-19): every edge starts with its VN's input LLR; with c2v = 0 (lambda = 1) in
     // the owners' registers the first gather yields exactly that.
+    // The channel term of a node (its LLR, or lambda = e^-L) is needed once per iteration, by one thread: it lives in
+    // device memory, a.ws_scr[frame][i][tid] — 64 KB per frame that stays in the L2 of the XCD — and not in 16 registers
+    // the check-node pass needs.
     uint32_t escaped = 0; // RATIO: running maximum of dm_ratio_key over the checked values (detmath.h)
-    double lam[NV];
+    double *const lam_ws = a.ws_scr + (frame * NV) * NT; // wave-uniform base: [i][tid]
 #pragma unroll
     for (int i = 0; i < NV; ++i)
     {
         const Reg2VnBlock vb = load_vn_block(R.vn_blocks, i * W + wave);
-        lam[i] = RATIO ? 1.0 : 0.0;
+        double lam_i = RATIO ? 1.0 : 0.0;
         if (lane < vb.count)
         {
             const double L = llr[R.vn_rank[(i * W + wave) * 64 + lane]];
@@ -168,15 +175,16 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
             {
                 if (!(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT))
                     escaped = ~0u;
-                lam[i] = dm_exp_clamped(0.0 - L);
-                lds[vb.tot_off + lane] = dm_ratio_div(1.0, lam[i]);
+                lam_i = dm_exp_clamped(0.0 - L);
+                lds[vb.tot_off + lane] = dm_ratio_div(1.0, lam_i);
             }
             else
             {
-                lam[i] = L;
+                lam_i = L;
                 lds[vb.tot_off + lane] = L;
             }
         }
+        lam_ws[i * NT + tid] = lam_i;
     }
 
     // ---- check-node side ----
@@ -220,7 +228,16 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
         uint32_t gather_mask = 0x3FFF8u, scatter_mask = 0x7FFF8u;
         const Reg2VnBlock *vn_blocks = R.vn_blocks;
         asm volatile("" : "+s"(gather_mask), "+s"(scatter_mask), "+s"(vn_blocks));
+        // (and for the words themselves: their rotated forms are loop invariants too)
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+#pragma unroll
+            for (int j = 0; j < MAXD; ++j)
+                asm volatile("" : "+v"(ew[k][j]));
         auto scatter = [&](auto round) {
+            // (opaque per call: otherwise round 1 reuses the 24 rotated-and-masked words of round 0, kept in registers
+            // across the variable-node round in between)
+            asm volatile("" : "+s"(scatter_mask));
 #pragma unroll
             for (int k = 0; k < KC; ++k)
 #pragma unroll
@@ -305,30 +322,120 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
              }()),
              ...);
         }(std::make_integer_sequence<int, KC>{});
-        scatter(std::integral_constant<uint32_t, 0>{});
-        REG2_TICK(2)
-        __syncthreads();
-        REG2_TICK(3)
+        // one node: the total (decoder.cpp:50-56) from its channel term and its column, in column file order
+        auto vn_total3 = [&](double l, double c0, double x1, double x2, uint32_t tot_byte, int i) {
+            double tot_entry, out_value;
+            if constexpr (RATIO)
+            {
+                double prod = l * c0; // lambda(total) = lambda(L_ch) * prod lambda(c2v_p)
+                prod *= x1;
+                prod *= x2;
+                const uint64_t bit = prod >= 1.0; // total LLR <= 0: the decision rides in the sign of the entry
+                const double tot = dm_ratio_div(1.0, prod); // rho(total)
+                tot_entry = dm_from_bits(dm_bits(tot) | (bit << 63));
+                if constexpr (WANT_LLR)
+                    out_value = 0.0 - dm_log(prod);
+            }
+            else
+            {
+                double out = l + c0;
+                out += x1;
+                out += x2;
+                tot_entry = out;
+                out_value = out;
+            }
+            *lds_abs<double>(tot_byte) = tot_entry;
+            if constexpr (WANT_LLR)
+                out_llr[P.rank_col[R.vn_rank[(i * W + wave) * 64 + lane]]] = out_value;
+        };
+        // UVN: block (round r, i) of this wave sits at entry  base + stride * (i * W + wave) + lane  (DevReg2Plan::vn_affine)
+        auto vn_fetch = [&]<int... Is>(std::integer_sequence<int, Is...>, auto base, double(&l)[sizeof...(Is)]) {
+            // scalar base + one 32-bit lane offset (opaque: otherwise eight 64-bit lane addresses are hoisted out of the loop)
+            uint32_t toff = static_cast<uint32_t>(tid) * 8u;
+            asm volatile("" : "+v"(toff));
+            ((l[Is] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lam_ws + (decltype(base)::value + Is) * NT) + toff)), ...);
+            __builtin_amdgcn_sched_barrier(0); // the loads stay here, ahead of the phase that covers their latency
+        };
+        auto vn_round_u = [&]<int... Js>(std::integer_sequence<int, Js...>, auto base, auto rnd, const double(&l_in)[sizeof...(Js)],
+                                         auto first) {
+            // sizeof...(Js) blocks of the round starting at its block `first`, in lock step; arrays below are indexed from 0
+            constexpr int r = decltype(rnd)::value, n = sizeof...(Js), j0 = decltype(first)::value;
+            [&]<int... Is>(std::integer_sequence<int, Is...>) {
+            const double(&l)[n] = l_in;
+            uint32_t a0 = R.vn_affine[r][0], s0 = R.vn_affine[r][1], a1 = R.vn_affine[r][2], s1 = R.vn_affine[r][3], a2 = R.vn_affine[r][4],
+                     s2 = R.vn_affine[r][5];
+            asm volatile("" : "+s"(a0), "+s"(s0), "+s"(a1), "+s"(s1), "+s"(a2), "+s"(s2)); // (not hoisted: 3 registers per block)
+            const uint32_t lw = static_cast<uint32_t>(lane) * 8u;
+            const uint32_t p0 = (a0 + s0 * wave) * 8u + lw, pr = (a1 + s1 * wave) * 8u + lw, pt = (a2 + s2 * wave) * 8u + lw;
+            double c0[n], x1[n], x2[n], prod[n];
+            ((c0[Is] = *lds_abs<const double>(p0 + (j0 + Is) * s0 * (W * 8u)), x1[Is] = *lds_abs<const double>(pr + (j0 + Is) * s1 * (W * 8u)),
+              x2[Is] = *lds_abs<const double>(pr + (j0 + Is) * s1 * (W * 8u) + 512u)),
+             ...);
+            __builtin_amdgcn_sched_barrier(0); // every read of the round in flight before the first product waits for one
+            if constexpr (RATIO)
+            {
+                // the blocks in lock step, one operation of each at a time: the dependent chain of a division
+                // (dm_ratio_div(1.0, prod), the same instruction sequence) is eight instructions long
+                ((prod[Is] = l[Is] * c0[Is]), ...); // lambda(total) = lambda(L_ch) * prod lambda(c2v_p), column file order
+                ((prod[Is] *= x1[Is]), ...);
+                ((prod[Is] *= x2[Is]), ...);
+                double rc[n], e[n];
+                ((rc[Is] = __builtin_amdgcn_rcp(prod[Is])), ...);
+                ((e[Is] = DM_FMA(-prod[Is], rc[Is], 1.0)), ...);
+                ((rc[Is] = DM_FMA(rc[Is], e[Is], rc[Is])), ...);
+                ((e[Is] = DM_FMA(-prod[Is], rc[Is], 1.0)), ...);
+                ((rc[Is] = DM_FMA(rc[Is], e[Is], rc[Is])), ...);
+                ((e[Is] = DM_FMA(-prod[Is], rc[Is], 1.0)), ...); // (the quotient 1.0 * r is r)
+                ((e[Is] = DM_FMA(e[Is], rc[Is], rc[Is])), ...);  // rho(total)
+                // total LLR <= 0 (prod >= 1): the decision rides in the sign of the entry
+                ((*lds_abs<double>(pt + (j0 + Is) * s2 * (W * 8u)) = dm_from_bits(dm_bits(e[Is]) | (static_cast<uint64_t>(prod[Is] >= 1.0) << 63))), ...);
+                if constexpr (WANT_LLR)
+                    ((out_llr[P.rank_col[R.vn_rank[((decltype(base)::value + j0 + Is) * W + wave) * 64 + lane]]] = 0.0 - dm_log(prod[Is])), ...);
+            }
+            else
+            {
+                ((prod[Is] = l[Is] + c0[Is]), ...); // sequential sum in column file order
+                ((prod[Is] += x1[Is]), ...);
+                ((prod[Is] += x2[Is]), ...);
+                ((*lds_abs<double>(pt + (j0 + Is) * s2 * (W * 8u)) = prod[Is]), ...);
+                if constexpr (WANT_LLR)
+                    ((out_llr[P.rank_col[R.vn_rank[((decltype(base)::value + j0 + Is) * W + wave) * 64 + lane]]] = prod[Is]), ...);
+            }
+        }(std::make_integer_sequence<int, n>{});
+        };
+        // a round two blocks at a time: four in lock step would hide more latency and need 20 registers more than the
+        // thread has (measured: the spills that buys cost more than the lock step gains)
+        auto vn_pairs = [&]<int... Ps>(std::integer_sequence<int, Ps...>, auto base, auto rnd, const double(&l)[2 * sizeof...(Ps)]) {
+            (([&] {
+                 const double lp[2] = {l[2 * Ps], l[2 * Ps + 1]};
+                 vn_round_u(std::integer_sequence<int, 0, 1>{}, base, rnd, lp, std::integral_constant<int, 2 * Ps>{});
+                 __builtin_amdgcn_sched_barrier(0);
+             }()),
+             ...);
+        };
         // ---- VN pass, APP and hard decision (decoder.cpp:48-64): totals of the two rounds ----
         auto vn_round = [&]<int... Is>(std::integer_sequence<int, Is...>, auto base) {
             (([&] {
                  constexpr int i = decltype(base)::value + Is;
                  const Reg2VnBlock vb = load_vn_block(vn_blocks, i * W + wave);
+                 uint32_t toff = static_cast<uint32_t>(tid) * 8u;
+                 asm volatile("" : "+v"(toff));
+                 const double lam_i = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lam_ws + i * NT) + toff);
                  if (lane < vb.count)
                  {
                      const double *c0 = lds + vb.p0_off + lane, *cr = lds + vb.prest_off + lane;
+                     if (vb.degree == 3) // unrolled: all loads in flight at once
+                     {
+                         const double x0 = c0[0], x1 = cr[0], x2 = cr[vb.count];
+                         vn_total3(lam_i, x0, x1, x2, (vb.tot_off + lane) * 8u, i);
+                         return;
+                     }
                      double tot_entry, out_value;
                      if constexpr (RATIO)
                      {
                          // lambda(total) = lambda(L_ch) * prod lambda(c2v_p), in column file order
-                         double prod = lam[i] * c0[0];
-                         if (vb.degree == 3) // the regular code's case, unrolled: all loads in flight at once
-                         {
-                             const double x1 = cr[0], x2 = cr[vb.count];
-                             prod *= x1;
-                             prod *= x2;
-                         }
-                         else if (vb.degree <= 3)
+                         double prod = lam_i * c0[0];
+                         if (vb.degree <= 3)
                              for (int p = 1; p < vb.degree; ++p)
                                  prod *= cr[(p - 1) * vb.count];
                          else
@@ -346,16 +453,9 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
                      }
                      else
                      {
-                         double out = lam[i] + c0[0]; // sequential sum in column file order
-                         if (vb.degree == 3)
-                         {
-                             const double x1 = cr[0], x2 = cr[vb.count];
-                             out += x1;
-                             out += x2;
-                         }
-                         else
-                             for (int p = 1; p < vb.degree; ++p)
-                                 out += cr[(p - 1) * vb.count];
+                         double out = lam_i + c0[0]; // sequential sum in column file order
+                         for (int p = 1; p < vb.degree; ++p)
+                             out += cr[(p - 1) * vb.count];
                          tot_entry = out;
                          out_value = out;
                      }
@@ -366,18 +466,49 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
              }()),
              ...);
         };
-        vn_round(std::make_integer_sequence<int, NV0>{}, std::integral_constant<int, 0>{});
-        REG2_TICK(4)
-        __syncthreads();
-        REG2_TICK(5)
-        scatter(std::integral_constant<uint32_t, 1>{});
-        REG2_TICK(6)
-        __syncthreads();
-        REG2_TICK(7)
-        vn_round(std::make_integer_sequence<int, NV1>{}, std::integral_constant<int, NV0>{});
-        REG2_TICK(8)
-        __syncthreads();
-        REG2_TICK(9)
+        if constexpr (UVN)
+        {
+            // the channel terms of a round come from device memory (L2): asked for a phase ahead, so that the mailbox
+            // writes and a barrier cover the latency
+            double l0[NV0], l1[NV1];
+            vn_fetch(std::make_integer_sequence<int, NV0>{}, std::integral_constant<int, 0>{}, l0);
+            scatter(std::integral_constant<uint32_t, 0>{});
+            REG2_TICK(2)
+            __syncthreads();
+            REG2_TICK(3)
+            vn_pairs(std::make_integer_sequence<int, NV0 / 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, l0);
+            vn_fetch(std::make_integer_sequence<int, NV1>{}, std::integral_constant<int, NV0>{}, l1);
+            REG2_TICK(4)
+            __syncthreads();
+            REG2_TICK(5)
+            scatter(std::integral_constant<uint32_t, 1>{});
+            REG2_TICK(6)
+            __syncthreads();
+            REG2_TICK(7)
+            vn_pairs(std::make_integer_sequence<int, NV1 / 2>{}, std::integral_constant<int, NV0>{}, std::integral_constant<int, 1>{}, l1);
+            REG2_TICK(8)
+            __syncthreads();
+            REG2_TICK(9)
+        }
+        else
+        {
+            scatter(std::integral_constant<uint32_t, 0>{});
+            REG2_TICK(2)
+            __syncthreads();
+            REG2_TICK(3)
+            vn_round(std::make_integer_sequence<int, NV0>{}, std::integral_constant<int, 0>{});
+            REG2_TICK(4)
+            __syncthreads();
+            REG2_TICK(5)
+            scatter(std::integral_constant<uint32_t, 1>{});
+            REG2_TICK(6)
+            __syncthreads();
+            REG2_TICK(7)
+            vn_round(std::make_integer_sequence<int, NV1>{}, std::integral_constant<int, NV0>{});
+            REG2_TICK(8)
+            __syncthreads();
+            REG2_TICK(9)
+        }
         ++I;
     }
 
@@ -462,21 +593,23 @@ int launch_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, void *s
     if (redo && (min_sum || !a.redo_list_in))
         return hipErrorInvalidValue;
     void (*k)(const DecodeArgs, const DevReg2Plan) = nullptr;
-    auto pick = [&]<bool UCN>(std::bool_constant<UCN>) {
+    // the regular code's instantiation (no switch over check-node degrees, straight-line variable-node rounds), or
+    // the generic one
+    auto pick = [&]<bool U>(std::bool_constant<U>) {
         if (min_sum)
-            k = want_llr ? decode_reg2_kernel<true, true, NT, KC, MAXD, NV0, NV1, false, false, UCN>
-                         : decode_reg2_kernel<true, false, NT, KC, MAXD, NV0, NV1, false, false, UCN>;
+            k = want_llr ? decode_reg2_kernel<true, true, NT, KC, MAXD, NV0, NV1, false, false, U, U>
+                         : decode_reg2_kernel<true, false, NT, KC, MAXD, NV0, NV1, false, false, U, U>;
         else if (ratio)
-            k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true, false, UCN>
-                         : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true, false, UCN>;
+            k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true, false, U, U>
+                         : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true, false, U, U>;
         else if (redo)
-            k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, true, UCN>
-                         : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, true, UCN>;
+            k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, true, U, U>
+                         : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, true, U, U>;
         else
-            k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, false, UCN>
-                         : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, false, UCN>;
+            k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, false, U, U>
+                         : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, false, U, U>;
     };
-    if (r.uniform_cn)
+    if (r.uniform_cn && r.uniform_vn)
         pick(std::true_type{});
     else
         pick(std::false_type{});
@@ -496,7 +629,7 @@ int launch_decode_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, 
 {
     if (a.n_frames == 0)
         return hipSuccess;
-    if (!a.ws_llr || !a.ws_hb)
+    if (!a.ws_llr || !a.ws_hb || !a.ws_scr) // ws_scr: [n_frames][(nv0 + nv1) * nt] channel terms
         return hipErrorInvalidValue;
     if (r.nt == 1024 && r.kc == 4 && r.maxd == 6 && r.nv0 == 4 && r.nv1 == 4)
         return launch_reg2<1024, 4, 6, 4, 4>(a, r, min_sum, stream);

@@ -422,6 +422,22 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
         }
     }
     r.uniform_cn = std::all_of(r.cn_deg.begin(), r.cn_deg.end(), [&](uint8_t d) { return d == maxd; });
+    r.uniform_vn = nv0 >= 2 && nv1 >= 2;
+    for (int rd = 0; rd < 2 && r.uniform_vn; ++rd)
+    {
+        const int nvr = rd ? nv1 : nv0;
+        auto blk = [&](int q) -> const Reg2VnBlock & { return r.vn_blocks[static_cast<size_t>(q / W + (rd ? nv0 : 0)) * W + q % W]; };
+        const Reg2VnBlock &b0 = blk(0), &b1 = blk(1);
+        uint32_t *af = r.vn_affine[rd];
+        af[0] = b0.p0_off, af[1] = b1.p0_off - b0.p0_off, af[2] = b0.prest_off, af[3] = b1.prest_off - b0.prest_off;
+        af[4] = b0.tot_off, af[5] = b1.tot_off - b0.tot_off;
+        for (int q = 0; q < nvr * W && r.uniform_vn; ++q)
+        {
+            const Reg2VnBlock &b = blk(q);
+            r.uniform_vn = b.count == kWaveSize && b.degree == 3 && b.p0_off == af[0] + af[1] * q && b.prest_off == af[2] + af[3] * q &&
+                           b.tot_off == af[4] + af[5] * q;
+        }
+    }
     r.ok = true;
     return r;
 }

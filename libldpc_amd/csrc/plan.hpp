@@ -143,6 +143,8 @@ struct Reg2Plan
     int nt = 0, kc = 0, maxd = 0, nv0 = 0, nv1 = 0;
     uint32_t e_max = 0, neutral = 0, lds_entries = 0;
     bool uniform_cn = false; // all kc * (nt/64) check-node blocks exist and have maxd edges: the kernel's UCN instantiation
+    bool uniform_vn = false; // all (nv0 + nv1) * (nt/64) variable-node blocks are full, of degree 3, at affine offsets:
+    uint32_t vn_affine[2][6] = {}; // per round {p0 base, stride, prest base, stride, tot base, stride} in entries per block
     // [(k*maxd + j)*nt + tid]: bits 3..17 = byte address the edge's VN total is gathered from, bits 18..31 = mailbox
     // entry the edge's c2v message is scattered to, bit 0 = the round of the edge's node, bit 1 = no edge.  Rotated
     // right by 15 and masked with 0x7FFF8 the word is the scatter byte address plus 0x20000 (round 1) or 0x40000 (no

@@ -4,7 +4,7 @@
 set -e -o pipefail
 name=${1:?name}; src=${2:?source under libldpc_amd/csrc}; extra=${3:-}
 cd "$(dirname "$0")/.."
-python3 -m libldpc_amd.build > /dev/null
+[ -n "$SKIP_PRODUCT_BUILD" ] || python3 -m libldpc_amd.build > /dev/null
 obj=$(python3 -c "from libldpc_amd import build; print(build.OBJ)")
 mkdir -p ab /tmp/ldpc_variant
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden $extra \

@@ -250,60 +250,70 @@ __global__ __launch_bounds__(1024) void polar_offsets_kernel(const uint32_t *blo
     }
 }
 
+// Registers: the kernel runs under the decode kernel of the previous batch, whose five waves per SIMD leave 32 VGPRs
+// of each SIMD lane free (512 - 5 x 96).  A wave that fits there starts in a slot the decoder cannot use; one that
+// does not waits for a decode workgroup to retire and keeps the next one out.  Hence the ballots live in LDS and the
+// second phase is a rolled loop with one instance of the polar arithmetic.
 __global__ __launch_bounds__(kScanThreads) void polar_compact_kernel(const uint64_t *raw, uint64_t n_trials,
                                                                      const uint64_t *block_offsets, uint64_t want,
                                                                      uint64_t *pairs_out, ScanResult *result)
 {
-    __shared__ int wave_cnt[kScanIters][kScanThreads / 64];
+    constexpr int kWaves = kScanThreads / 64;
+    __shared__ unsigned long long ballot[kScanIters * kWaves]; // accepted lanes of (it, wave): trials in ascending order
+    __shared__ int first[kScanIters * kWaves];                 // accepted trials of the block before (it, wave)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t off = block_offsets[blockIdx.x];
     if (off >= want) // nothing this block holds is needed
         return;
     const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanBlock;
-    bool acc[kScanIters];
-    int before[kScanIters]; // accepted lanes below this one in its wave
-#pragma unroll
+#pragma unroll 2
     for (int it = 0; it < kScanIters; ++it)
     {
-        acc[it] = trial_accepted(raw, base + it * kScanThreads + tid, n_trials);
-        unsigned long long m = __ballot(acc[it]);
-        before[it] = __popcll(m & ((1ull << lane) - 1));
+        const unsigned long long m = __ballot(trial_accepted(raw, base + it * kScanThreads + tid, n_trials));
         if (lane == 0)
-            wave_cnt[it][wave] = __popcll(m);
+            ballot[it * kWaves + wave] = m;
     }
     __syncthreads();
-    // trials are ordered (it, wave, lane) = ascending trial index
-    int run = 0;
-#pragma unroll
+    if (tid == 0)
+    {
+        int run = 0;
+        for (int i = 0; i < kScanIters * kWaves; ++i)
+        {
+            first[i] = run;
+            run += __popcll(ballot[i]);
+        }
+    }
+    __syncthreads();
+#pragma clang loop unroll(disable)
     for (int it = 0; it < kScanIters; ++it)
     {
-#pragma unroll
-        for (int w = 0; w < kScanThreads / 64; ++w)
+        const unsigned long long m = ballot[it * kWaves + wave];
+        if (!(m >> lane & 1))
+            continue;
+        const uint64_t rank = off + first[it * kWaves + wave] + __popcll(m & ((1ull << lane) - 1));
+        if (rank >= want)
+            continue;
+        const uint64_t t = base + it * kScanThreads + tid;
+        if (pairs_out)
         {
-            if (w == wave && acc[it])
-            {
-                uint64_t rank = off + run + before[it];
-                if (rank < want)
-                {
-                    uint64_t t = base + it * kScanThreads + tid;
-                    if (pairs_out)
-                    {
-                        // the accepted trial leaves here as its two normals (libstdc++ normal_distribution, polar
-                        // method: y*mult is returned first, x*mult saved for the next call), so the decode launch
-                        // finds finished variates instead of a log/divide/sqrt chain at the head of every frame
-                        const ulonglong2 u = *reinterpret_cast<const ulonglong2 *>(raw + 2 * t);
-                        const PolarTrial tr = polar_trial(u.x, u.y);
-                        const double mult = __builtin_sqrt(-2 * dm_log(tr.r2) / tr.r2);
-                        ulonglong2 o;
-                        o.x = dm_bits(tr.y * mult), o.y = dm_bits(tr.x * mult);
-                        *reinterpret_cast<ulonglong2 *>(pairs_out + 2 * rank) = o;
-                    }
-                    if (rank == want - 1)
-                        result->trials_used = t + 1;
-                }
-            }
-            run += wave_cnt[it][w];
+            // the accepted trial leaves here as its two normals (libstdc++ normal_distribution, polar method: y*mult is
+            // returned first, x*mult saved for the next call), so the decode launch finds finished variates instead of
+            // a log/divide/sqrt chain at the head of every frame
+            const ulonglong2 u = *reinterpret_cast<const ulonglong2 *>(raw + 2 * t);
+            const PolarTrial tr = polar_trial(u.x, u.y);
+            __builtin_amdgcn_sched_barrier(0); // (stage by stage: the scheduler's interleaving costs 20 registers)
+            const double lg = dm_log(tr.r2);
+            __builtin_amdgcn_sched_barrier(0);
+            const double q = -2 * lg / tr.r2;
+            __builtin_amdgcn_sched_barrier(0);
+            const double mult = __builtin_sqrt(q);
+            __builtin_amdgcn_sched_barrier(0);
+            ulonglong2 o;
+            o.x = dm_bits(tr.y * mult), o.y = dm_bits(tr.x * mult);
+            *reinterpret_cast<ulonglong2 *>(pairs_out + 2 * rank) = o;
         }
+        if (rank == want - 1)
+            result->trials_used = t + 1;
     }
 }
 

@@ -376,8 +376,10 @@ def main():
     leader = rank == 0 and not os.environ.get("LDPC_BENCH_CHILD")
 
     # ---- legs that need child processes: before this process (or its rank children) touches a GPU ----
+    # (N = 1 only: the counters describe one GPU's kernel, the CPU baseline is a per-box figure; at N > 1 the other ranks
+    # would sit in the rendezvous while rank 0 profiles)
     legs = {}
-    if leader:
+    if leader and args.gpus == 1:
         if not args.no_pmc and args.config != "1":
             legs["pmc"] = pmc_passes(args.config, args.batch or w["batch"])
         if not args.no_cpu_baseline:

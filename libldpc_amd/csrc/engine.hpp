@@ -119,6 +119,8 @@ class MtStream
     static constexpr uint32_t kStateCap = ChunkTable::kCap;
     void reset(uint64_t seed);
     uint64_t seed() const { return seed_; }
+    // chunks per generator workgroup (1 or 4, kernels.hpp launch_mt_generate)
+    void set_pack(int chunks_per_workgroup) { pack_ = chunks_per_workgroup; }
     // Generate raw outputs [first, first+count) of the stream; returns a device pointer to word `first`.
     const uint64_t *generate(uint64_t first, uint64_t count, void *stream);
 
@@ -126,6 +128,7 @@ class MtStream
     void ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream);
     const uint64_t *device_poly(unsigned m, void *stream);
     uint64_t seed_ = 0;
+    int pack_ = 1;
     bool seeded_ = false;
     ChunkTable table_;
     unsigned polys_uploaded_ = 0;

@@ -157,9 +157,10 @@ int launch_bec(const BecArgs &a, void *stream);
 constexpr int kMtN = 312;
 // Generate chunk_words raw (tempered) outputs per chunk: chunk c starts from states[c*312..] and
 // writes out[c*chunk_words ..]; the state that follows the LAST chunk is written to next_last[0..312)
-// (may be null).
+// (may be null).  chunks_per_workgroup: 1, or 4 to keep the generator on a quarter of the compute units (for decode
+// kernels that own a whole CU per frame).
 int launch_mt_generate(const uint64_t *states, uint64_t *next_last, uint64_t *out, uint32_t n_chunks,
-                       uint32_t chunk_words, void *stream);
+                       uint32_t chunk_words, int chunks_per_workgroup, void *stream);
 // Jump: for task t, dst_states[t] = src_states[t] advanced by the polynomial `poly` (19937 coefficient
 // bits, kJumpPolyWords words: 312 + zero padding).
 int launch_mt_jump(const uint64_t *src_states, uint64_t *dst_states, const uint64_t *poly, uint32_t n_tasks,

@@ -51,20 +51,29 @@ __device__ __forceinline__ void mt_regenerate(uint64_t *x, int lane)
     }
 }
 
-// One workgroup of three waves per chunk.  The twist has 156-way parallelism: words 0..155 of the next
+// Three waves per chunk, kGenChunks chunks per workgroup.  The twist has 156-way parallelism: words 0..155 of the next
 // window depend only on the current window, words 156..311 on the current window and the new words 0..155.
-// Thread t < 156 produces words t and t+156; reads and writes of a half are separated by workgroup barriers.
+// Thread t < 156 of a chunk's three waves produces words t and t+156; reads and writes of a half are separated by
+// workgroup barriers.  Several chunks share a workgroup so that a batch's 82 chunks occupy 21 compute units for the
+// length of the serial chain and not 82: the register-resident decode kernel owns a whole CU per frame, and every CU
+// that hosts a generator wave is lost to it for that long.
+// (kGenChunks = 1 when the decode kernel shares its CUs anyway: packed chunks lengthen the serial chain, which then
+// outlasts the headline decode kernel it runs under)
 constexpr int kGenThreads = 192;
-__global__ __launch_bounds__(kGenThreads) void mt_generate_kernel(const uint64_t *states, uint64_t *next_last,
-                                                                  uint64_t *out, uint32_t chunk_words)
+template <int kGenChunks>
+__global__ __launch_bounds__(kGenThreads *kGenChunks) void mt_generate_kernel(const uint64_t *states, uint64_t *next_last,
+                                                                              uint64_t *out, uint32_t chunk_words, uint32_t n_chunks)
 {
-    __shared__ uint64_t x[kMtN];
-    const int t = threadIdx.x;
-    const bool act = t < 156;
-    const uint64_t c = blockIdx.x;
+    __shared__ uint64_t xs[kGenChunks][kMtN];
+    const int t = threadIdx.x % kGenThreads, sub = threadIdx.x / kGenThreads;
+    const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kGenChunks + sub;
+    const bool live = c < n_chunks; // (the last workgroup may hold fewer chunks; its idle waves still meet the barriers)
+    const bool act = live && t < 156;
+    uint64_t *x = xs[sub];
     const uint64_t *s = states + c * kMtN;
-    for (int k = t; k < kMtN; k += kGenThreads)
-        x[k] = s[k];
+    if (live)
+        for (int k = t; k < kMtN; k += kGenThreads)
+            x[k] = s[k];
     __syncthreads();
     uint64_t *o = out + c * chunk_words;
     const uint32_t blocks = chunk_words / kMtN;
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(kGenThreads) void mt_generate_kernel(const uint64_t
         }
         __syncthreads();
     }
-    if (next_last && c + 1 == gridDim.x) // the window after the last chunk = start state of the next chunk
+    if (next_last && c + 1 == n_chunks) // the window after the last chunk = start state of the next chunk
         for (int k = t; k < kMtN; k += kGenThreads)
             next_last[k] = x[k];
 }
@@ -320,14 +329,18 @@ __global__ __launch_bounds__(kScanThreads) void polar_compact_kernel(const uint6
 } // namespace
 
 int launch_mt_generate(const uint64_t *states, uint64_t *next_last, uint64_t *out, uint32_t n_chunks,
-                       uint32_t chunk_words, void *stream)
+                       uint32_t chunk_words, int chunks_per_workgroup, void *stream)
 {
     if (n_chunks == 0)
         return hipSuccess;
     if (chunk_words % kMtN != 0)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mt_generate_kernel, dim3(n_chunks), dim3(kGenThreads), 0, static_cast<hipStream_t>(stream), states,
-                       next_last, out, chunk_words);
+    if (chunks_per_workgroup >= 4)
+        hipLaunchKernelGGL(mt_generate_kernel<4>, dim3((n_chunks + 3) / 4), dim3(kGenThreads * 4), 0, static_cast<hipStream_t>(stream),
+                           states, next_last, out, chunk_words, n_chunks);
+    else
+        hipLaunchKernelGGL(mt_generate_kernel<1>, dim3(n_chunks), dim3(kGenThreads), 0, static_cast<hipStream_t>(stream), states,
+                           next_last, out, chunk_words, n_chunks);
     return hipGetLastError();
 }
 

@@ -71,7 +71,7 @@ def make_code_by_degrees(path, vn_degs, cn_degs, rng):
 
 
 def test_irregular_code_totals_form(tmp_path):
-    """The second register-resident kernel (totals form, kernels_reg2.hip) on a code that is NOT regular: check nodes
+    """The second register-resident kernel (totals form, kernels_reg2_impl.hpp) on a code that is NOT regular: check nodes
     of degree 5 and 6 (the generic instantiation with its switch over the degree, partly filled blocks), variable nodes
     of degree 2 and 3; 20800 messages = 166 KB, beyond LDS.  Bit for bit against the det oracle, sum-product with and
     without early termination (ratio form, second pass, LLR domain with the saturated form) and min-sum."""

@@ -1,7 +1,7 @@
-for c in 2,2 1,4 1,8 1,16 2,16 1,32; do
-  echo -n "VN_COST=$c: "
-  LDPC_AMD_VN_COST=$c timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 60 2>&1 | tail -1 | grep -o "ms_per_step[^,]*\|kernel_ms_avg[^,]*" | tr '\n' ' '
-  echo
-done
-echo -n "VN_COST=2,2 again: "
-LDPC_AMD_VN_COST=2,2 timeout -k 10 300 python3 bench.py --no-cpu-baseline --steps 60 2>&1 | tail -1 | grep -o "ms_per_step[^,]*\|kernel_ms_avg[^,]*" | tr '\n' ' '
+#!/bin/bash
+# VN block dealing weights (plan.cpp, LDPC_AMD_VN_COST=a,b: cost of a block = a*degree + b) on the headline workload
+for r in 1 2; do for c in 2,2 2,4 1,4 1,5 2,9; do
+  echo -n "VN_COST=$c (round $r): "
+  LDPC_AMD_VN_COST=$c timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-pmc --steps 60 2>/dev/null | tail -1 | python3 -c "
+import sys,json; j=json.loads(sys.stdin.read()); print('ms/step %.3f  kernel %.3f'%(j['ms_per_step'], j['roofline'].get('kernel_ms_avg') or 0))"
+done; done

@@ -85,6 +85,7 @@ def test_code_info_and_plan(h8k_file):
     assert d.lds_resident and d.lds_bytes <= 40960  # four frames per 160 KiB CU
     d8 = libldpc_amd.HipDecoder(h8k_file)
     assert (d8.nc, d8.mc, d8.nnz, d8.max_degree) == (8192, 4096, 24576, 6) and not d8.lds_resident
+    assert d8.residency == "registers" and d8.register_form == "totals" and d.register_form is None
 
 
 def test_missing_file_is_reported():
@@ -191,3 +192,30 @@ def test_reference_pyldpc_wrapper_outputs():
         assert [int(v) for v in c.encode(np.array(e["info"]))] == e["codeword"]
     for e in fx["syndrome"]:
         assert [int(v) for v in c.syndrome(np.array(e["word"]))] == e["syndrome"]
+
+
+def test_totals_form_plan_layout(h8k_file, tmp_path):
+    """The LDS layout and packed edge words of the second register-resident kernel (plan.cpp build_reg2_plan), checked on
+    the host by tools/reg2_plan_stats.cpp: every edge lands in its own round's mailbox entry and in the trash entry in
+    the other round (the kernel's address arithmetic replayed), no entry has two writers, totals are distinct, 160 KB
+    hold; the (3,6) n=8192 code takes the regular-code instantiation, an irregular code the generic one; the bank-aware
+    placement keeps its conflict levels."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_random_codes import make_code_by_degrees
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "reg2_plan_stats")
+    subprocess.check_call(["g++", "-O2", "-std=c++20", "-I" + os.path.join(root, "libldpc_amd", "csrc"),
+                           os.path.join(root, "tools", "reg2_plan_stats.cpp"), os.path.join(root, "libldpc_amd", "csrc", "plan.cpp"),
+                           os.path.join(root, "libldpc_amd", "csrc", "code.cpp"), "-o", exe])
+    irr = make_code_by_degrees(str(tmp_path / "irr.txt"), [2] * 3008 + [3] * 4928, [5] * 560 + [6] * 3000, np.random.default_rng(11))
+    for path, regular in ((h8k_file, "yes"), (irr, "no")):
+        p = subprocess.run([exe, path], stdout=subprocess.PIPE, text=True)
+        assert p.returncode == 0, p.stdout
+        assert f"invariant violations: 0   regular-code instantiation: {regular}" in p.stdout
+        gather = float(re.search(r"gather: ([0-9.]+)", p.stdout).group(1))
+        scatter = [float(x) for x in re.search(r"round 0 ([0-9.]+), round 1 ([0-9.]+)", p.stdout).groups()]
+        assert gather <= 4.1 and max(scatter) <= 6.5, p.stdout  # natural order: 7.0 and 8.8
+    # a code with a degree-1 variable node is left to the messages form
+    leaf = make_code_by_degrees(str(tmp_path / "leaf.txt"), [1] * 64 + [2] * 2976 + [3] * 4928, [5] * 560 + [6] * 3000, np.random.default_rng(12))
+    p = subprocess.run([exe, leaf], stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 1 and "plan refused" in p.stdout

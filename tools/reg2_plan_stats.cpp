@@ -63,9 +63,55 @@ int main(int argc, char **argv)
                     s_cycles[rd] += *std::max_element(cnt, cnt + 16);
                 }
         }
+    // ---- invariants of the layout (plan.hpp): every mailbox entry below e_max is the target of at most one edge per
+    // round, every edge of a node scatters into that node's round, gathers address a total or the neutral entry,
+    // columns without an edge carry the "no edge" flag, everything fits 160 KB ----
+    int bad = 0;
+    {
+        std::vector<int> hit[2] = {std::vector<int>(r.e_max, 0), std::vector<int>(r.e_max, 0)};
+        size_t edges = 0;
+        for (size_t i = 0; i < r.edge_w.size(); ++i)
+        {
+            const uint32_t ew = r.edge_w[i];
+            const uint32_t gather = (ew & 0x3FFF8u) >> 3, scatter = ew >> 18, rd = ew & 1u;
+            if (ew & 2u)
+            {
+                bad += gather != r.neutral;
+                continue;
+            }
+            ++edges;
+            bad += scatter >= r.e_max || gather >= r.lds_entries || gather == kReg2TrashEntry;
+            if (scatter < r.e_max)
+                ++hit[rd][scatter];
+            // the address arithmetic of the kernel: own round -> the entry, other round -> the trash entry
+            for (uint32_t round = 0; round < 2; ++round)
+            {
+                uint32_t at = (((ew >> 15) | (ew << 17)) & 0x7FFF8u) - round * 0x20000u;
+                at = std::min(at, kReg2TrashEntry * 8u);
+                bad += at != (round == rd ? scatter * 8u : kReg2TrashEntry * 8u);
+            }
+        }
+        for (int rd = 0; rd < 2; ++rd)
+            for (int h : hit[rd])
+                bad += h > 1;
+        bad += edges != static_cast<size_t>(plan.nnz);
+        bad += static_cast<size_t>(r.lds_entries) * 8 + 64 > 160 * 1024 || r.neutral <= kReg2TrashEntry;
+        // every variable-node block: its column and its total inside the regions, totals of different nodes distinct
+        std::vector<int> tot_hit(r.lds_entries, 0);
+        for (const Reg2VnBlock &b : r.vn_blocks)
+            for (uint32_t l = 0; l < b.count; ++l)
+            {
+                bad += b.tot_off + l >= r.lds_entries || b.tot_off + l == kReg2TrashEntry || b.tot_off + l == r.neutral;
+                if (b.tot_off + l < r.lds_entries)
+                    bad += ++tot_hit[b.tot_off + l] > 1;
+                bad += b.p0_off + l >= r.e_max;
+                bad += b.degree > 1 && b.prest_off + static_cast<uint32_t>(b.degree - 2) * b.count + l >= r.e_max;
+            }
+    }
+    std::printf("invariant violations: %d   regular-code instantiation: %s\n", bad, r.uniform_cn && r.uniform_vn ? "yes" : "no");
     std::printf("gather: %.2f LDS cycles per wave instruction (2 = no conflicts)\n", g_cycles / g_inst);
     std::printf("scatter: round 0 %.2f, round 1 %.2f LDS cycles per wave instruction (4 = no conflicts)\n", s_cycles[0] / s_inst,
                 s_cycles[1] / s_inst);
     std::printf("lds entries %u (%u bytes), e_max %u, neutral %u\n", r.lds_entries, r.lds_entries * 8 + 16, r.e_max, r.neutral);
-    return 0;
+    return bad ? 2 : 0;
 }

@@ -63,6 +63,21 @@ def test_fixture_is_what_libm_says_here(gold, fn):
     check(fn, a, b, orc.math_eval(fn, a, b, det=True), ref)
 
 
+@pytest.mark.parametrize("fn", ["boxplus", "cn_llr4", "cn_llr6"])
+def test_host_header_vs_libm_on_live_points(fn):
+    """detmath.h compiled for the host against libm / the libm box-plus chain on fresh points — saturated check nodes
+    (magnitudes to 1e13, the edges of the rule: smallest input around 40, spread around 600) and saturated box-plus
+    operands included (orc.math_points).  The device side of the same comparison needs a GPU (below)."""
+    n = 1 << 15 if fn.startswith("cn_") else 1 << 18
+    a, b = orc.math_points(fn, n, seed=11)
+    with np.errstate(all="ignore"):
+        check(fn, a, b, orc.math_eval(fn, a, b, det=True), orc.math_eval(fn, a, b))
+    if fn.startswith("cn_"):
+        mu, amax = np.abs(a).min(axis=1), np.abs(a).max(axis=1)
+        sat = (mu >= 40) & (amax - mu <= 600)
+        assert 0.2 < sat.mean() < 0.7 and ((amax > 600) & ~sat).any() and ((amax <= 600) & ~sat).any()  # all three forms taken
+
+
 @pytest.fixture(scope="module")
 def dec():
     import libldpc_amd

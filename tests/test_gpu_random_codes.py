@@ -91,6 +91,34 @@ def test_irregular_code_totals_form(tmp_path):
     assert 0 < r["iters"].min()
 
 
+@pytest.mark.parametrize("name,vn,cn,residency", [
+    ("lds_regular_3_6", [3] * 600, [6] * 300, "lds"),
+    ("lds_mixed", [3] * 500 + [4] * 100 + [6] * 50, [4] * 300 + [5] * 120 + [8] * 50, "lds"),
+    ("mem_wide_cn20", [3] * 800, [20] * 120, "memory"),
+    ("mem_wide_cn40_24", [3] * 800, [40] * 30 + [24] * 50, "memory"),
+])
+def test_saturated_check_nodes_in_a_whole_decode(name, vn, cn, residency, tmp_path):
+    """Sum-product WITHOUT early termination on codes without degree-1 variable nodes: after convergence the LLRs
+    double with every iteration and the check nodes take the saturated form (detmath.h dm_sat_*) — in the register
+    tiles of the LDS-resident decoder (through its hand-over) and in the wide-node scratch form of the memory-resident
+    one.  Bit for bit against the det oracle, and the run must really have saturated."""
+    import libldpc_amd
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    path = make_code_by_degrees(str(tmp_path / f"{name}.txt"), vn, cn, rng)
+    code = orc.Code(path)
+    d = libldpc_amd.HipDecoder(path)
+    assert d.residency == residency, d.residency
+    for x, iters in ((10.0, 45), (5.0, 30)):
+        d.stream_begin("AWGN", 9, x)
+        r = d.stream_decode(6, early_term=False, iterations=iters, decoding="BP", want=OUT)
+        o = code.run_frames("AWGN", x, seed=9, skip=0, count=6, early_term=False, iters=iters, math=orc.MATH_DET)
+        for k in OUT:
+            assert np.array_equal(r[k], o[k].astype(r[k].dtype)), (name, x, k)
+    d.stream_begin("AWGN", 9, 10.0)
+    r = d.stream_decode(6, early_term=False, iterations=45, decoding="BP", want=("llr_out", "bit_errors"))
+    assert (r["bit_errors"] == 0).all() and np.abs(r["llr_out"]).min() > 1e6
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_random_code_bit_exact(case, tmp_path):
     import libldpc_amd

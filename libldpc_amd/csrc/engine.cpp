@@ -282,7 +282,7 @@ const uint64_t *MtStream::device_poly(unsigned m, void *stream)
     return base + static_cast<size_t>(m) * kJumpPolyWords;
 }
 
-const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream)
+const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream, int buffer)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (count == 0)
@@ -292,7 +292,7 @@ const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream)
     ensure_states(c_lo, c_hi, stream);
     const uint32_t n = static_cast<uint32_t>(c_hi - c_lo);
     uint64_t *st = static_cast<uint64_t *>(states_.get());
-    uint64_t *raw = static_cast<uint64_t *>(raw_.reserve(sizeof(uint64_t) * kChunkWords * n));
+    uint64_t *raw = static_cast<uint64_t *>(raw_[buffer & 1].reserve(sizeof(uint64_t) * kChunkWords * n));
     const uint64_t base = table_.base();
     if (n == 1)
     {
@@ -701,7 +701,8 @@ void Engine::run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const 
     a.early_term = p.early_term;
     a.deg1_compat = bec_deg1_compat;
     a.n_frames = n;
-    a.raw = noise_.generate(raw_next_, n * nct, stream);
+    int raw_buffer = 0;
+    a.raw = noise_raw_async(raw_next_, n * nct, stream, raw_buffer);
     a.eps = x_;
     a.codeword = codeword;
     a.iters = st.route(out.iters, stage_iters_, 4 * n);
@@ -712,6 +713,7 @@ void Engine::run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const 
     prof_mark(0, s);
     check(launch_bec(a, s), "bec");
     prof_mark(0, s);
+    noise_raw_release(raw_buffer, stream);
     if (out.codeword)
     {
         if (codeword)
@@ -876,6 +878,30 @@ void Engine::ensure_rng_stream()
     }
 }
 
+const uint64_t *Engine::noise_raw_async(uint64_t first, uint64_t count, void *stream, int &buffer)
+{
+    ensure_rng_stream();
+    hipStream_t s = static_cast<hipStream_t>(rng_stream_), user = static_cast<hipStream_t>(stream);
+    const int buf = pp_;
+    pp_ ^= 1;
+    // the launch that last read this buffer (two batches ago) must be done before it is refilled
+    if (pairs_in_use_[buf])
+        check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev_pairs_free_[buf]), 0), "wait raw free");
+    prof_mark(1, s);
+    const uint64_t *raw = noise_.generate(first, count, s, buf);
+    prof_mark(1, s);
+    check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_ready_[buf]), s), "event");
+    check(hipStreamWaitEvent(user, static_cast<hipEvent_t>(ev_pairs_ready_[buf]), 0), "wait raw ready");
+    buffer = buf;
+    return raw;
+}
+
+void Engine::noise_raw_release(int buffer, void *stream)
+{
+    check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_free_[buffer]), static_cast<hipStream_t>(stream)), "event");
+    pairs_in_use_[buffer] = true;
+}
+
 // Locate the accepted polar pairs that supply the normals of frames [frame_pos_, frame_pos_+n).
 void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream)
 {
@@ -990,10 +1016,12 @@ void Engine::stream_decode(const DecParams &p, uint64_t n_frames, const BatchOut
         else if (chan_ == kBsc)
         {
             a.mode = kModeBsc;
-            a.raw = noise_.generate(raw_next_, n * nct, stream);
+            int raw_buffer = 0;
+            a.raw = noise_raw_async(raw_next_, n * nct, stream, raw_buffer);
             a.eps = x_, a.delta = delta_;
             a.shorten_llr = delta_; // channel.cpp:152
             run_decode(a, p, o, n, stream);
+            noise_raw_release(raw_buffer, stream);
             raw_next_ += n * nct;
         }
         else
@@ -1165,10 +1193,12 @@ Engine::ShardStep Engine::stream_decode_sharded(Comm &comm, const DecParams &p, 
         {
             a.mode = kModeBsc;
             a.codeword = cw;
-            a.raw = noise_.generate(st.first * nct, st.n * nct, stream);
+            int raw_buffer = 0;
+            a.raw = noise_raw_async(st.first * nct, st.n * nct, stream, raw_buffer);
             a.eps = x_, a.delta = delta_;
             a.shorten_llr = delta_; // channel.cpp:152
             run_decode(a, p, out, st.n, stream);
+            noise_raw_release(raw_buffer, stream);
         }
         else
         {

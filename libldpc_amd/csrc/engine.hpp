@@ -122,7 +122,8 @@ class MtStream
     // chunks per generator workgroup (1 or 4, kernels.hpp launch_mt_generate)
     void set_pack(int chunks_per_workgroup) { pack_ = chunks_per_workgroup; }
     // Generate raw outputs [first, first+count) of the stream; returns a device pointer to word `first`.
-    const uint64_t *generate(uint64_t first, uint64_t count, void *stream);
+    // raw words [first, first + count) on `stream`, into one of the stream object's two output buffers
+    const uint64_t *generate(uint64_t first, uint64_t count, void *stream, int buffer = 0);
 
   private:
     void ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream);
@@ -132,7 +133,7 @@ class MtStream
     bool seeded_ = false;
     ChunkTable table_;
     unsigned polys_uploaded_ = 0;
-    DeviceBuffer states_, raw_, poly_;
+    DeviceBuffer states_, raw_[2], poly_;
 };
 
 class Engine
@@ -196,6 +197,11 @@ class Engine
   private:
     void bind_device();
     void ensure_rng_stream();
+    // BSC / BEC: the batch's raw words generated on the engine's side stream into one of two buffers, ordered before the
+    // caller's stream by an event — so that the generation for batch s+1 runs under the decode of batch s, as the AWGN
+    // path's noise stream does; noise_raw_release() after the launch that reads them
+    const uint64_t *noise_raw_async(uint64_t first, uint64_t count, void *stream, int &buffer);
+    void noise_raw_release(int buffer, void *stream);
     void upload_plan();
     void run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, uint64_t n, void *stream);
     void run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const uint8_t *codeword, void *stream);

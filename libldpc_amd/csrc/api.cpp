@@ -103,7 +103,18 @@ void ldpc_setup(const char *pcFile, const char *genFile, int *n, int *m, int *nc
 {
     try
     {
-        g_engine = std::make_unique<Engine>(pcFile ? pcFile : "", genFile ? genFile : "", 0);
+        // the six reference symbols carry no device argument: LDPC_AMD_DEVICE picks the GPU of the process-global engine
+        // (read at every ldpc_setup; default 0), e.g. one pyLDPC process per GPU of an 8-GPU node
+        int device = 0;
+        if (const char *e = std::getenv("LDPC_AMD_DEVICE"))
+        {
+            char *end = nullptr;
+            const long v = std::strtol(e, &end, 10);
+            if (end == e || *end != '\0' || v < 0 || v > 1023)
+                throw std::runtime_error(std::string("LDPC_AMD_DEVICE is not a device index: ") + e);
+            device = static_cast<int>(v);
+        }
+        g_engine = std::make_unique<Engine>(pcFile ? pcFile : "", genFile ? genFile : "", device);
     }
     catch (const std::exception &e)
     {

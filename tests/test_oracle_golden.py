@@ -186,3 +186,24 @@ def test_bulk_reference_counters(golden_bulk):
         o = code.run_frames("AWGN", -4.0, seed=0, skip=int(f), count=1, math=orc.MATH_DET)
         different += int(o["bit_errors"][0] != ref_be[f] or not np.array_equal(o["hard"][0], h))
     assert len(frames) > 40 and different <= 1, different
+
+
+def test_shape_fixtures_bit_exact(tmp_path):
+    """tests/golden/ref_shapes.npz (make_shapes.py: the reference on a weight-20 check-node code and on an irregular
+    7936-column code): the libm-mode oracle reproduces iteration counts, bit errors, hard decisions and LLR-out doubles
+    bit for bit; the regenerated code files have the recorded sha256."""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_shapes
+    fx = np.load(os.path.join(orc.GOLDEN, "ref_shapes.npz"))
+    codes = {}
+    for name in make_shapes.CODES:
+        path = make_shapes.code_file(name, str(tmp_path))
+        assert hashlib.sha256(open(path, "rb").read()).digest() == fx[f"sha256/{name}"].tobytes(), name
+        codes[name] = orc.Code(path)
+    for key, (code, ch, dec, it, early, seed, x, skip, cnt) in make_shapes.CASES.items():
+        r = codes[code].run_frames(ch, x, seed=seed, skip=skip, count=cnt, min_sum=(dec == "BP_MS"), early_term=bool(early), iters=it)
+        assert np.array_equal(r["iters"], fx[f"{key}/iters"]) and np.array_equal(r["bit_errors"], fx[f"{key}/bit_errors"]), key
+        assert np.array_equal(np.packbits(r["hard"], axis=1), fx[f"{key}/hard_packed"]), key
+        assert np.array_equal(r["llr_out"], fx[f"{key}/llr_out"]), key

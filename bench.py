@@ -13,13 +13,18 @@ N GPUs: one process per GPU.  Under `python -m torch.distributed.run` the ranks 
 `python bench.py --gpus N` starts the N rank processes itself (before anything in this process touches a GPU) and
 relays rank 0's line.  Every step is one range of the single noise stream shared out over the ranks (weak scaling:
 N x 65 536 frames per step): each rank generates and scans only its own piece of the raw mt19937_64 stream, one RCCL
-all-gather of 8 bytes per rank places it in the pair sequence, and the counters {frames, fec, bec, iters, converged}
-are all-reduced once per step.
+all-gather of 24 bytes per rank places it in the pair sequence, and the counters {frames, fec, bec, iters, converged}
+are summed on each rank's device and reduced ONCE after the last step.  At every N the line carries, per rank and as
+min / max over ranks: decode-kernel and noise-stream milliseconds, host time inside the exchange and waiting for the noise
+stream, frames per step, communicator set-up seconds (outside the timed region), and the min / median / max step time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline      the binding on-chip ceiling of the dominant kernel from SQ / TCC counters collected by rocprofv3 in
-                separate passes of the same workload inside this run (tools/pmc_probe.py), frac <= 1; the survey's
-                algorithmic-bytes figure is reported as algorithmic_equiv_GBs and is not a physical bandwidth
+  roofline      of the dominant kernel, from SQ / TCC counters collected by rocprofv3 in separate passes of the same
+                workload inside this run (tools/pmc_probe.py).  Sum-product configurations: WORK-NORMALISED — binary64
+                operations retired per second against the 78.6 TFLOP/s vector peak (bound "valu-fp64"), with the
+                instruction mix per edge-update and the SIMD-busy share (valu_busy) beside it; the other ceilings (LDS
+                array, HBM bytes) in `ceilings`.  The survey's algorithmic-bytes figure is reported as
+                algorithmic_equiv_GBs and is not a physical bandwidth
   cpu_baseline  the reference CLI (oracle/_ref/ldpcsim_ref) on this box's host cores, bounded sample, with the
                 one-thread rate beside it
 """
@@ -44,8 +49,12 @@ from libldpc_amd import workloads  # noqa: E402  (host-only module: no GPU, no t
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 CLOCK_HZ = 2.4e9            # max shader clock
 N_SIMD, N_CU = 1024, 256
+FP64_PEAK_TFLOPS = N_SIMD * 16 * 2 * CLOCK_HZ / 1e12  # 78.6: 16 fp64 FMA lanes per SIMD and clock (MI355X_MICROARCH.md)
 SQ_PASS = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT",
            "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"]
+# the instruction mix of the same kernel (its own pass): binary64 arithmetic by class, integer, conversions, scalar
+MIX_PASS = ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+            "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT", "SQ_INSTS_SALU"]
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -66,11 +75,14 @@ def pmc_passes(cfg, batch, steps=2, warmup=1):
              str(warmup), "--batch", str(batch)]
     agg, meta = {}, {}
     try:
-        for name, counters in (("sq", SQ_PASS), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+        for name, counters in (("sq", SQ_PASS), ("mix", MIX_PASS), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
             out = os.path.join(tmp, name)
             p = subprocess.run([rocprof, "--pmc", *counters, "-d", out, "-o", "run", "--output-format", "csv", "--", *probe],
                                cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
             if p.returncode != 0:
+                if name == "mix":  # (the mix is additional evidence: without it the line still carries the other ceilings)
+                    meta["mix_error"] = f"rocprofv3 pass mix failed (rc {p.returncode}): {p.stderr[-200:]}"
+                    continue
                 return {"error": f"rocprofv3 pass {name} failed (rc {p.returncode}): {p.stderr[-300:]}"}
             rows = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
@@ -92,8 +104,8 @@ def pmc_passes(cfg, batch, steps=2, warmup=1):
                 agg[c] = sum(d.get(c, 0.0) for d in timed) / len(timed)
             if name == "sq":
                 agg["ns"] = sum(d["ns"] for d in timed) / len(timed)
-                meta = {"kernel": dom.replace("ldpc_amd::(anonymous namespace)::", "").replace("void ", "").split("(")[0],
-                        "launches_averaged": len(timed)}
+                meta.update({"kernel": dom.replace("ldpc_amd::(anonymous namespace)::", "").replace("void ", "").split("(")[0],
+                             "launches_averaged": len(timed)})
             line = [l for l in p.stdout.splitlines() if l.startswith("{")]
             if line and name == "sq":
                 meta["probe"] = json.loads(line[-1])
@@ -135,12 +147,34 @@ def roofline_from(pmc, kernel_ms, eu_per_launch, w):
     }
     for v in ceilings.values():
         v["frac"] = v["achieved"] / v["peak"]
-    bound = max(ceilings, key=lambda k: ceilings[k]["frac"])
-    b = ceilings[bound]
+    eu = max(pmc.get("probe", {}).get("edge_updates", 0) / max(pmc.get("probe", {}).get("steps", 1), 1), 1)
+    mix = None
+    if "SQ_INSTS_VALU_FMA_F64" in c:
+        # Work-normalised: binary64 operations the kernel retires (an FMA counts two, everything else one; a wave instruction
+        # counts 64 lanes) against 78.6 TFLOP/s.  Unlike the busy share above this does NOT rise when the kernel executes
+        # redundant instructions.  v_rcp_f64 (TRANS) occupies its SIMD 16 cycles, the others 4: fp64_pipe_frac prices that.
+        add, mul, fma, trans = (c[k] for k in MIX_PASS[:4])
+        f64 = add + mul + fma + trans
+        flops = 64.0 * (add + mul + 2.0 * fma + trans)
+        mix = {"achieved": flops / t / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / t / 1e12 / FP64_PEAK_TFLOPS,
+               "fp64_share_of_valu_instructions": f64 / max(c["SQ_INSTS_VALU"], 1.0),
+               "fp64_pipe_frac_of_kernel_cycles": (4.0 * (add + mul + fma) + 16.0 * trans) / (N_SIMD * cycles),
+               "lane_instructions_per_edge_update": {"fp64_add": add * 64 / eu, "fp64_mul": mul * 64 / eu, "fp64_fma": fma * 64 / eu,
+                                                     "fp64_reciprocal": trans * 64 / eu, "int32": c[MIX_PASS[4]] * 64 / eu,
+                                                     "int64": c[MIX_PASS[5]] * 64 / eu, "convert": c[MIX_PASS[6]] * 64 / eu,
+                                                     "all_valu": c["SQ_INSTS_VALU"] * 64 / eu, "salu_per_valu": c[MIX_PASS[7]] / max(c["SQ_INSTS_VALU"], 1.0)}}
+        ceilings["fp64"] = mix
+    sum_product = w["decoding"] == "BP" and w["channel"] != "BEC" and not w.get("fast")
+    if mix and sum_product:
+        bound, b = "valu-fp64", mix  # sum-product: binary64 arithmetic is the work; the other ceilings stay in `ceilings`
+    else:
+        bound = max((k for k in ceilings if k != "fp64"), key=lambda k: ceilings[k]["frac"])
+        b = ceilings[bound]
     return {"bound": bound, "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"],
+            "valu_busy": ceilings["valu"]["busy_frac_of_kernel_cycles"],
             "traffic": hbm_bytes, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run: (2*FETCH_SIZE + WRITE_SIZE) KB",
             "kernel": pmc.get("kernel"), "profiled_kernel_ms": c["ns"] * 1e-6, "shader_clock_GHz": clk / 1e9,
-            "ceilings": ceilings, **base}
+            "mix_error": pmc.get("mix_error"), "ceilings": ceilings, **base}
 
 
 def cpu_baseline(w, budget_s=18.0):
@@ -276,15 +310,20 @@ def run_rank(args, w):
     # grows with N.  The library's communicator is RCCL (its unique id travels over torch.distributed); the rehearsal
     # on one GPU uses the host shared-memory transport, RCCL refuses two ranks on one device.
     comm = None
+    comm_init_s = 0.0
     if world > 1:
+        t_init = time.perf_counter()
         if os.environ.get("LDPC_BENCH_ONE_GPU"):
             comm = libldpc_amd.Comm(rank, world, shm_name=f"/ldpc_bench_{os.environ.get('MASTER_PORT', '0')}")
         else:
             box = [libldpc_amd.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
-            comm = libldpc_amd.Comm(rank, world, device=local_rank, unique_id=box[0])
+            comm = libldpc_amd.Comm(rank, world, device=local_rank, unique_id=box[0])  # ncclCommInitRank: outside the timed region
+        comm_init_s = time.perf_counter() - t_init
     dec.stream_begin(w["channel"], 0, w["x"])
     span = [None, 0]  # frames covered by the timed steps: [first, end)
+    own = []          # frames this rank decoded per timed step
+    tot = torch.zeros(5, dtype=torch.int64, device=dev)
 
     def step():
         if comm is None:
@@ -297,26 +336,34 @@ def run_rank(args, w):
         if span[0] is None:
             span[0] = st[0]
         span[1] = st[0] + st[1]
-        # {frames, fec, bec, iters, converged} of the rank's frames, summed by the library in one launch on the same stream
+        own.append(n_own)
+        # {frames, fec, bec, iters, converged} of the rank's frames, summed by the library in one launch on the same stream and
+        # added to the rank's running totals on the device: nothing crosses ranks per step but the library's own 24-byte
+        # all-gather.  The counters are reduced ONCE, after the last step (north_star: "a single RCCL reduce of FER/BER
+        # counters") — and no second communicator is in use while the library's collectives run.
         dec.batch_counters(iters_d.data_ptr(), be_d.data_ptr(), n_own, iters, early, c.data_ptr(), stream)
-        if dist is not None and backend != "nccl":
-            return shard.reduce_counters(c.cpu(), dist).to(dev)
-        return shard.reduce_counters(c, dist)  # the counters of the step: 5 x int64 over xGMI
+        tot.add_(c)
 
-    tot = torch.zeros(5, dtype=torch.int64, device=dev)
     for _ in range(W):  # same ops as the timed loop, so every kernel's code object is loaded beforehand
-        tot += step()
+        step()
     torch.cuda.synchronize()
-    dec.last_ms(0), dec.last_ms(1)  # drop the warm-up launches' events
+    for k in range(4):
+        dec.last_ms(k)  # drop the warm-up launches' events / timers
     tot.zero_()
     span[0] = None
+    own.clear()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]  # per-step spread without a host sync per step
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(K):
-        tot += step()
+    marks[0].record()
+    for k in range(K):
+        step()
+        marks[k + 1].record()
     torch.cuda.synchronize()
+    if comm is not None:  # the one reduce of the counters: 5 x int64 per rank through the library's communicator
+        tot = torch.from_numpy(comm.all_gather(tot.cpu().numpy().astype("uint64")).astype("int64").sum(axis=0))
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -324,9 +371,20 @@ def run_rank(args, w):
     # HIP events around every decode launch (on the launch stream) and every noise-stream refill (on the engine's
     # internal stream), queued during the loop and read back here: mean over the K timed steps
     kernel_ms, rng_ms = dec.last_ms(0), dec.last_ms(1)
+    exch_ms, wait_ms = dec.last_ms(2), dec.last_ms(3)
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(K))
+    mine = {"rank": rank, "kernel_ms_avg": kernel_ms, "rng_ms_avg": rng_ms, "host_in_exchange_ms_avg": exch_ms,
+            "host_wait_noise_ms_avg": wait_ms, "comm_init_s": comm_init_s, "frames": int(sum(own)),
+            "frames_per_step_min": int(min(own)), "frames_per_step_max": int(max(own)),
+            "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1]},
+            "jump_tasks": int(dec.jump_tasks)}
+    per_rank = [mine]
     t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        per_rank = box
     dt = float(t.item())
     frames, fec, bec, it_sum, conv = (int(v) for v in tot.tolist())
     d = workloads.code_dims(w)
@@ -334,12 +392,24 @@ def run_rank(args, w):
     edge_updates = (it_sum + conv) * d["nnz"]
     if comm is not None:
         comm.close()
-    return ({"frames": frames, "dt": dt, "edge_updates": edge_updates, "kernel_ms": kernel_ms,
+
+    def over(key):
+        vals = [r[key] for r in per_rank]
+        return {"min": min(vals), "max": max(vals)}
+    ranks = {"kernel_ms_avg": over("kernel_ms_avg"), "rng_ms_avg": over("rng_ms_avg"),
+             "host_in_exchange_ms_avg": over("host_in_exchange_ms_avg"), "host_wait_noise_ms_avg": over("host_wait_noise_ms_avg"),
+             "comm_init_s": over("comm_init_s"), "frames": over("frames"),
+             "frames_per_step": {"min": min(r["frames_per_step_min"] for r in per_rank), "max": max(r["frames_per_step_max"] for r in per_rank)},
+             "step_ms": {"min": min(r["step_ms"]["min"] for r in per_rank), "median_max_over_ranks": max(r["step_ms"]["median"] for r in per_rank),
+                         "max": max(r["step_ms"]["max"] for r in per_rank)},
+             "per_rank": per_rank}
+    return ({"frames": frames, "dt": dt, "edge_updates": edge_updates, "kernel_ms": max(r["kernel_ms_avg"] for r in per_rank),
              "extra": {"fer": fec / frames, "ber": bec / (frames * d["nc"]), "avg_iter": it_sum / frames, "rng_ms_avg": rng_ms,
+                       "step_ms": ranks["step_ms"], "ranks": ranks,
                        "counters": {"frames": frames, "fec": fec, "bec": bec, "iters": it_sum, "converged": conv},
                        "timed_frame_span": span, "residency": dec.residency,
                        "exchange": "none (one rank)" if world == 1 else ("host shared memory (one-GPU rehearsal)" if os.environ.get("LDPC_BENCH_ONE_GPU")
-                                                                        else "RCCL: u64 all-gather per step (pair counts) + 5 x int64 all-reduce (counters)")}},
+                                                                        else "RCCL: 24-byte all-gather per step (accepted-pair counts + status), one 5 x int64 gather of the counters after the last step")}},
             rank, world, dist)
 
 

@@ -140,7 +140,9 @@ uint64_t ldpc_hip_stream_raw_draws(const ldpc_hip_ctx *ctx);
 int ldpc_hip_synchronize(ldpc_hip_ctx *ctx, void *hip_stream);
 
 /* time kernels with HIP events: which = 0 the decode launches (recorded on the launch stream), 1 the noise-stream
-   refills (mt19937_64 generate + polar scan, recorded on the library's internal stream).  Event pairs are queued
+   refills (jump-ahead + generator + slab table, recorded on the library's internal stream); host wall-clock: which = 2 the
+   time the calling thread spent inside the ranks' exchange (all-gather) of a sharded step, 3 the time it waited for the
+   noise stream's result (both: mean milliseconds per step since the previous call).  Event pairs are queued
    per launch; ldpc_hip_last_ms waits for them and returns the MEAN duration in milliseconds of the launches since
    the previous call (so a caller that reads it once per launch sees that launch, and a caller that reads it after
    a loop does not serialise the overlap of the noise stream with the decode) */
@@ -164,11 +166,19 @@ int ldpc_hip_selftest_division(ldpc_hip_ctx *ctx, uint64_t n, uint64_t seed, uin
    a, b, out are HOST buffers of n (x D) doubles; b may be NULL for one-operand functions. */
 int ldpc_hip_selftest_math(ldpc_hip_ctx *ctx, int fn, uint64_t n, const double *a, const double *b, double *out);
 
-/* host-only self-test of the noise stream's chunk-state table bookkeeping (no GPU needed): replays n_requests sequential
-   generate requests of chunks_per_request chunks each, starting at chunk first_chunk, and returns the largest table row
-   any step reads or writes (must be <= 8192, the last row of the table), or UINT64_MAX if a request was left without a
-   valid row */
-uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per_request, uint64_t n_requests);
+/* host-only self-tests of the noise stream's chunk-state bookkeeping (libldpc_amd/csrc/mtstates.hpp; no GPU needed): the
+   planned operations are replayed on a symbolic table in which every row records which chunk's state it holds.
+   chunk_table: n_requests requests of chunks_per_request consecutive chunks each, `gap` chunks apart (0 = one rank reading
+   the stream front to back; > 0 = a rank of a sharded BSC / BEC stream), starting at first_chunk.  Returns the number of
+   jump-ahead tasks issued in total, or UINT64_MAX if an operation read a row without a valid state or a request was left
+   without its rows.
+   shard_table: `steps` sharded AWGN steps of rank `rank` of `world` (piece_chunks chunks + the margin chunk per rank and
+   step).  Returns the jump-ahead tasks of the steps AFTER the first (and their launches in *launches): piece_chunks + 1
+   per step whatever the world size — or UINT64_MAX as above. */
+uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per_request, uint64_t n_requests, uint64_t gap);
+uint64_t ldpc_hip_selftest_shard_table(int world, int rank, uint32_t piece_chunks, uint64_t steps, uint64_t *launches);
+/* jump-ahead tasks (one task = one chunk start state advanced by one polynomial) this context's noise stream has launched */
+uint64_t ldpc_hip_jump_tasks(const ldpc_hip_ctx *ctx);
 
 /* the simulation loop of ldpc_sim::start (ldpcsim.cpp:97-263) on one context; totals[4*i..] =
    {frames, fec, bec, iters} per channel point.  Returns the number of channel points, <0 on error. */
@@ -191,16 +201,22 @@ int ldpc_hip_comm_unique_id(uint8_t id[128]);
 ldpc_hip_comm *ldpc_hip_comm_create(int rank, int world, int device, const uint8_t id[128]);
 /* host shared-memory communicator; `name` ("/something") is the same on every rank and unique to the job */
 ldpc_hip_comm *ldpc_hip_comm_create_shm(int rank, int world, const char *name);
+/* one process standing in for rank `rank` of `world`, no transport: every rank's slot of an all-gather is answered with the
+   caller's own payload.  For cost probes of the sharded step on one GPU (tools/shard_probe.py), not for results. */
+ldpc_hip_comm *ldpc_hip_comm_create_echo(int rank, int world);
 void ldpc_hip_comm_destroy(ldpc_hip_comm *comm);
 /* recv[q*bytes ..) = rank q's send[0 .. bytes): host buffers, bytes a multiple of 8 and at most 256 */
 int ldpc_hip_comm_allgather(ldpc_hip_comm *comm, const void *send, void *recv, uint64_t bytes);
 
-/* frames the output buffers of ldpc_hip_stream_decode_sharded must hold for a step of target_frames frames */
-uint64_t ldpc_hip_shard_capacity(uint64_t target_frames, int world);
+/* frames the output buffers of ldpc_hip_stream_decode_sharded must hold for a step of target_frames frames: a bound (every
+   trial of a piece accepted), not a statistical estimate */
+uint64_t ldpc_hip_shard_capacity(const ldpc_hip_ctx *ctx, uint64_t target_frames, int world);
 /* this rank's share of the next global step of about target_frames frames of the stream (all ranks call it with the same
-   arguments).  AWGN: the step is a range of the raw mt19937_64 stream cut into `world` pieces; each rank generates and
-   scans its own piece only, one all-gather of the accepted-pair counts tells every rank where its piece starts in the
-   pair sequence, and a frame belongs to the rank whose piece holds its first pair.  BSC / BEC: even split.
+   arguments).  AWGN: the step is a range of the raw mt19937_64 stream cut into `world` pieces of whole generator chunks;
+   each rank generates its own piece only (its chunk start states are the previous step's advanced by one polynomial), one
+   all-gather of the accepted-pair counts tells every rank where its piece starts in the pair sequence, and a frame belongs
+   to the rank whose piece holds its first pair.  The step holds whatever frames its raw range holds (at least one chunk
+   per rank).  BSC / BEC: even split.  A failure on any rank makes every rank return an error from the same call.
    step[0..3] = first frame and frame count of the global step, first frame and frame count of this rank. */
 int ldpc_hip_stream_decode_sharded(ldpc_hip_ctx *ctx, ldpc_hip_comm *comm, decoder_param dec, uint64_t target_frames,
                                    const ldpc_hip_out *out, uint64_t step[4], void *hip_stream);

@@ -86,11 +86,13 @@ def load_library(path=LIB_PATH):
     L.ldpc_hip_comm_create.argtypes = [i32, i32, i32, vp]
     L.ldpc_hip_comm_create_shm.restype = vp
     L.ldpc_hip_comm_create_shm.argtypes = [i32, i32, ct.c_char_p]
+    L.ldpc_hip_comm_create_echo.restype = vp
+    L.ldpc_hip_comm_create_echo.argtypes = [i32, i32]
     L.ldpc_hip_comm_destroy.argtypes = [vp]
     L.ldpc_hip_comm_allgather.restype = i32
     L.ldpc_hip_comm_allgather.argtypes = [vp, vp, vp, u64]
     L.ldpc_hip_shard_capacity.restype = u64
-    L.ldpc_hip_shard_capacity.argtypes = [u64, i32]
+    L.ldpc_hip_shard_capacity.argtypes = [vp, u64, i32]
     L.ldpc_hip_stream_decode_sharded.restype = i32
     L.ldpc_hip_stream_decode_sharded.argtypes = [vp, vp, decoder_param, u64, ct.POINTER(ldpc_hip_out), vp, vp]
     L.ldpc_hip_simulate_sharded.restype = i32
@@ -99,7 +101,11 @@ def load_library(path=LIB_PATH):
     L.ldpc_hip_selftest_math.restype = i32
     L.ldpc_hip_selftest_math.argtypes = [vp, i32, u64, vp, vp, vp]
     L.ldpc_hip_selftest_chunk_table.restype = u64
-    L.ldpc_hip_selftest_chunk_table.argtypes = [u64, u64, u64]
+    L.ldpc_hip_selftest_chunk_table.argtypes = [u64, u64, u64, u64]
+    L.ldpc_hip_selftest_shard_table.restype = u64
+    L.ldpc_hip_selftest_shard_table.argtypes = [i32, i32, ct.c_uint32, u64, vp]
+    L.ldpc_hip_jump_tasks.restype = u64
+    L.ldpc_hip_jump_tasks.argtypes = [vp]
     L.ldpc_hip_simulate.restype = i32
     L.ldpc_hip_simulate.argtypes = [vp, decoder_param, channel_param, simulation_param, ct.POINTER(sim_results_t),
                                     vp, ct.POINTER(ct.c_bool), i32]
@@ -129,10 +135,12 @@ class Comm:
     """The exchange between the ranks of a sharded simulation (include/ldpc_amd.h part 3): RCCL when `unique_id` (128
     bytes from Comm.unique_id() on rank 0) is given, host shared memory when `shm_name` is."""
 
-    def __init__(self, rank, world, device=0, unique_id=None, shm_name=None, lib=LIB_PATH):
+    def __init__(self, rank, world, device=0, unique_id=None, shm_name=None, echo=False, lib=LIB_PATH):
         self.lib = load_library(lib)
         self.rank, self.world = int(rank), int(world)
-        if shm_name is not None:
+        if echo:  # one process standing in for one rank of `world` (cost probes): no transport
+            self.handle = self.lib.ldpc_hip_comm_create_echo(self.rank, self.world)
+        elif shm_name is not None:
             self.handle = self.lib.ldpc_hip_comm_create_shm(self.rank, self.world, shm_name.encode())
         else:
             buf = (ct.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
@@ -236,7 +244,7 @@ class HipDecoder:
         return bufs
 
     def shard_capacity(self, target_frames, world):
-        return int(self.lib.ldpc_hip_shard_capacity(int(target_frames), int(world)))
+        return int(self.lib.ldpc_hip_shard_capacity(self.ctx, int(target_frames), int(world)))
 
     def stream_decode_sharded(self, comm, target_frames, early_term=True, iterations=50, decoding="BP",
                               want=("iters", "bit_errors"), out=None, stream=None):
@@ -257,7 +265,15 @@ class HipDecoder:
 
     @property
     def stream_raw_draws(self):
-        return self.lib.ldpc_hip_stream_raw_draws(self.ctx)
+        n = self.lib.ldpc_hip_stream_raw_draws(self.ctx)
+        if n == 2**64 - 1:
+            raise RuntimeError("ldpc_hip_stream_raw_draws: " + self.lib.ldpc_hip_last_error().decode())
+        return n
+
+    @property
+    def jump_tasks(self):
+        """jump-ahead tasks the context's noise stream has launched so far"""
+        return self.lib.ldpc_hip_jump_tasks(self.ctx)
 
     def synchronize(self, stream=None):
         self._check(self.lib.ldpc_hip_synchronize(self.ctx, stream), "ldpc_hip_synchronize")
@@ -282,7 +298,7 @@ class HipDecoder:
         return bad.value
 
     MATH_FNS = ("exp", "log", "boxplus", "ratio_div", "ratio_rho", "ratio_lambda", "e_combine", "exp_clamped", "boxplus_exp",
-                "boxplus_log", "cn_ratio3", "cn_ratio4", "cn_ratio5", "cn_ratio6", "cn_ratio8", "cn_llr4", "cn_llr6")
+                "boxplus_log", "cn_ratio3", "cn_ratio4", "cn_ratio5", "cn_ratio6", "cn_ratio8", "cn_llr4", "cn_llr6", "cn_ratio3s", "cn_ratio4s")
 
     def selftest_math(self, fn, a, b=None):
         """The device arithmetic of detmath.h / device_cn.hpp on host arrays: fn is a name of MATH_FNS."""

@@ -288,7 +288,12 @@ int ldpc_hip_stream_decode(ldpc_hip_ctx *ctx, decoder_param dec, uint64_t n, con
 }
 
 uint64_t ldpc_hip_stream_frame(const ldpc_hip_ctx *ctx) { return ctx->eng->stream_frame(); }
-uint64_t ldpc_hip_stream_raw_draws(const ldpc_hip_ctx *ctx) { return ctx->eng->stream_raw_draws(); }
+uint64_t ldpc_hip_stream_raw_draws(const ldpc_hip_ctx *ctx)
+{
+    uint64_t n = ~0ull; // (AWGN: one generator pass locates the last consumed trial; UINT64_MAX on error)
+    guarded([&] { n = ctx->eng->stream_raw_draws(); });
+    return n;
+}
 
 int ldpc_hip_synchronize(ldpc_hip_ctx *ctx, void *hip_stream)
 {
@@ -388,32 +393,66 @@ int ldpc_hip_selftest_math(ldpc_hip_ctx *ctx, int fn, uint64_t n, const double *
     });
 }
 
-uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per_request, uint64_t n_requests)
+// host-only replay of the chunk-state bookkeeping (mtstates.hpp) on a symbolic table: every row records which chunk's state
+// it holds; an operation that reads a row without a valid state, or a request that ends without its rows, fails the replay
+namespace
 {
-    // host-only replay of MtStream's table bookkeeping: sequential requests, as a long Monte-Carlo run issues them
-    ChunkTable t;
-    uint64_t max_row = 0, c = first_chunk;
-    std::vector<ChunkTableOp> ops;
+struct SymbolicTable
+{
+    std::vector<int64_t> row; // chunk id, -1 = nothing valid
+    uint64_t tasks = 0, launches = 0;
+    explicit SymbolicTable(size_t n) : row(n, -1) {}
+    bool apply(const std::vector<StateOp> &ops)
+    {
+        for (const StateOp &op : ops)
+            switch (op.kind)
+            {
+            case StateOp::kUpload0: row[op.dst] = 0; break;
+            case StateOp::kCopy:
+                if (row[op.src] < 0)
+                    return false;
+                row[op.dst] = row[op.src];
+                break;
+            case StateOp::kJump:
+            {
+                std::vector<int64_t> src(op.n);
+                for (uint32_t i = 0; i < op.n; ++i) // all tasks of a launch may read before any of them writes, or after
+                {
+                    src[i] = row[(op.src + i) % op.mod];
+                    if (src[i] < 0)
+                        return false;
+                    for (uint32_t k = 0; k < op.n; ++k) // a task's source must not be another task's destination
+                        if (k != i && (op.dst + k) % op.mod == (op.src + i) % op.mod)
+                            return false;
+                }
+                for (uint32_t i = 0; i < op.n; ++i)
+                    row[(op.dst + i) % op.mod] = src[i] + static_cast<int64_t>(op.stride);
+                tasks += op.n, ++launches;
+                break;
+            }
+            }
+        return true;
+    }
+};
+} // namespace
+
+uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per_request, uint64_t n_requests, uint64_t gap)
+{
+    StateRing t;
+    SymbolicTable sym(StateRing::kTotalRows);
+    uint64_t c = first_chunk;
+    std::vector<StateOp> ops;
     try
     {
-        for (uint64_t i = 0; i < n_requests; ++i, c += chunks_per_request)
+        for (uint64_t i = 0; i < n_requests; ++i, c += chunks_per_request + gap)
         {
             ops.clear();
             t.ensure(c, c + chunks_per_request, ops);
-            for (const ChunkTableOp &op : ops)
-                if (op.kind == ChunkTableOp::kRebase)
-                    max_row = std::max<uint64_t>(max_row, op.a);
-                else if (op.kind == ChunkTableOp::kJump)
-                    max_row = std::max<uint64_t>(max_row, 2ull * op.a - 1);
-            if (c < t.base() || c + chunks_per_request - t.base() > t.ready())
-                return ~0ull; // a requested chunk has no valid row
-            max_row = std::max<uint64_t>(max_row, c + chunks_per_request - 1 - t.base());
-            const int64_t nr = t.next_row(c + chunks_per_request);
-            if (nr >= 0)
-            {
-                max_row = std::max<uint64_t>(max_row, static_cast<uint64_t>(nr));
-                t.note_next_written(c + chunks_per_request);
-            }
+            if (!sym.apply(ops))
+                return ~0ull;
+            for (uint64_t k = c; k < c + chunks_per_request; ++k)
+                if (sym.row[k % StateRing::kRows] != static_cast<int64_t>(k))
+                    return ~0ull; // a requested chunk has no valid row
         }
     }
     catch (const std::exception &e)
@@ -421,7 +460,42 @@ uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per
         g_err = e.what();
         return ~0ull;
     }
-    return max_row;
+    return sym.tasks;
+}
+
+uint64_t ldpc_hip_selftest_shard_table(int world, int rank, uint32_t piece_chunks, uint64_t steps, uint64_t *launches)
+{
+    StridedTable t;
+    SymbolicTable sym(StridedTable::kMaxRows + 2);
+    std::vector<StateOp> ops;
+    const uint32_t n = piece_chunks + 1;
+    const uint64_t stride = static_cast<uint64_t>(world) * piece_chunks;
+    uint64_t tasks_after_first = 0, launches_after_first = 0;
+    try
+    {
+        for (uint64_t s = 0; s < steps; ++s)
+        {
+            const uint64_t first = s * stride + static_cast<uint64_t>(rank) * piece_chunks;
+            ops.clear();
+            t.position(first, n, stride, ops);
+            const uint64_t t0 = sym.tasks, l0 = sym.launches;
+            if (!sym.apply(ops))
+                return ~0ull;
+            for (uint32_t i = 0; i < n; ++i)
+                if (sym.row[i] != static_cast<int64_t>(first + i))
+                    return ~0ull;
+            if (s > 0)
+                tasks_after_first += sym.tasks - t0, launches_after_first += sym.launches - l0;
+        }
+    }
+    catch (const std::exception &e)
+    {
+        g_err = e.what();
+        return ~0ull;
+    }
+    if (launches)
+        *launches = launches_after_first;
+    return tasks_after_first;
 }
 
 int ldpc_hip_comm_unique_id(uint8_t id[128])
@@ -453,6 +527,18 @@ ldpc_hip_comm *ldpc_hip_comm_create_shm(int rank, int world, const char *name)
     return c;
 }
 
+ldpc_hip_comm *ldpc_hip_comm_create_echo(int rank, int world)
+{
+    ldpc_hip_comm *c = nullptr;
+    if (guarded([&] {
+            auto p = std::make_unique<ldpc_hip_comm>();
+            p->comm = make_echo_comm(rank, world);
+            c = p.release();
+        }) != 0)
+        return nullptr;
+    return c;
+}
+
 void ldpc_hip_comm_destroy(ldpc_hip_comm *comm) { delete comm; }
 
 int ldpc_hip_comm_allgather(ldpc_hip_comm *comm, const void *send, void *recv, uint64_t bytes)
@@ -460,7 +546,8 @@ int ldpc_hip_comm_allgather(ldpc_hip_comm *comm, const void *send, void *recv, u
     return guarded([&] { comm->comm->all_gather(send, recv, bytes); });
 }
 
-uint64_t ldpc_hip_shard_capacity(uint64_t target_frames, int world) { return Engine::shard_capacity(target_frames, world < 1 ? 1 : world); }
+uint64_t ldpc_hip_shard_capacity(const ldpc_hip_ctx *ctx, uint64_t target_frames, int world) { return ctx->eng->shard_capacity(target_frames, world < 1 ? 1 : world); }
+uint64_t ldpc_hip_jump_tasks(const ldpc_hip_ctx *ctx) { return ctx->eng->noise_jump_tasks(); }
 
 int ldpc_hip_stream_decode_sharded(ldpc_hip_ctx *ctx, ldpc_hip_comm *comm, decoder_param dec, uint64_t target_frames,
                                    const ldpc_hip_out *out, uint64_t step[4], void *hip_stream)

@@ -141,8 +141,11 @@ class RcclComm final : public Comm
 struct ShmSeg
 {
     static constexpr int kMaxRanks = 64;
+    static constexpr uint64_t kMagic = 0x6c6470635f616d64ull; // "ldpc_amd"
     std::atomic<uint64_t> seq[kMaxRanks];
+    std::atomic<uint64_t> magic; // set by rank 0 once the object is sized and zero-filled
     std::atomic<uint32_t> attached;
+    std::atomic<uint32_t> go;    // set by rank 0 when every rank has attached to THIS object (then the name is unlinked)
     char data[2][kMaxRanks][Comm::kMaxBytes];
 };
 
@@ -154,42 +157,83 @@ class ShmComm final : public Comm
         if (world < 1 || world > ShmSeg::kMaxRanks || rank < 0 || rank >= world)
             throw std::runtime_error("ShmComm: bad rank / world size");
         rank_ = rank, world_ = world;
-        int fd = -1;
         const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+        auto map = [&](int fd) {
+            void *p = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (p == MAP_FAILED)
+                throw std::runtime_error("ShmComm: mmap failed");
+            return static_cast<ShmSeg *>(p);
+        };
         if (rank == 0)
         {
-            (void)shm_unlink(name.c_str());
-            fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            (void)shm_unlink(name.c_str()); // an object of this name left by an aborted job (names get reused)
+            const int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
             if (fd < 0 || ftruncate(fd, sizeof(ShmSeg)) != 0)
                 throw std::runtime_error("ShmComm: cannot create " + name);
-        }
-        else
-            while (true) // wait for rank 0 to create and size the object
+            seg_ = map(fd); // a fresh object is zero-filled: every seq starts at 0
+            seg_->magic.store(ShmSeg::kMagic, std::memory_order_release);
+            seg_->attached.fetch_add(1);
+            while (seg_->attached.load() < static_cast<uint32_t>(world)) // everyone is in before the name goes away
             {
-                fd = shm_open(name.c_str(), O_RDWR, 0600);
-                struct stat st;
-                if (fd >= 0 && fstat(fd, &st) == 0 && st.st_size >= static_cast<off_t>(sizeof(ShmSeg)))
-                    break;
-                if (fd >= 0)
-                    close(fd);
                 if (std::chrono::steady_clock::now() > deadline)
-                    throw std::runtime_error("ShmComm: timed out waiting for " + name);
-                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                {
+                    (void)shm_unlink(name.c_str());
+                    throw std::runtime_error("ShmComm: timed out waiting for the other ranks");
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
             }
-        void *p = mmap(nullptr, sizeof(ShmSeg), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        close(fd);
-        if (p == MAP_FAILED)
-            throw std::runtime_error("ShmComm: mmap failed");
-        seg_ = static_cast<ShmSeg *>(p); // a fresh object is zero-filled: every seq starts at 0
-        seg_->attached.fetch_add(1);
-        while (seg_->attached.load() < static_cast<uint32_t>(world)) // everyone is in before rank 0 may unlink the name
+            seg_->go.store(1, std::memory_order_release);
+            (void)shm_unlink(name.c_str());
+            return;
+        }
+        // A rank may find an object of the same name that an ABORTED earlier job left behind (its rank 0 never unlinked it)
+        // before this job's rank 0 has replaced it.  Such an object never gets the go-ahead: after a short wait the rank lets
+        // go of it and opens the name again, until it sits on the object this job's rank 0 created.
+        for (;;)
         {
             if (std::chrono::steady_clock::now() > deadline)
-                throw std::runtime_error("ShmComm: timed out waiting for the other ranks");
-            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                throw std::runtime_error("ShmComm: timed out waiting for " + name);
+            const int fd = shm_open(name.c_str(), O_RDWR, 0600);
+            struct stat st;
+            if (fd < 0 || fstat(fd, &st) != 0 || st.st_size < static_cast<off_t>(sizeof(ShmSeg)))
+            {
+                if (fd >= 0)
+                    close(fd);
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+                continue;
+            }
+            ShmSeg *seg = map(fd);
+            bool ok = false;
+            if (seg->magic.load(std::memory_order_acquire) == ShmSeg::kMagic)
+            {
+                seg->attached.fetch_add(1);
+                const auto patience = std::chrono::steady_clock::now() + std::chrono::seconds(3);
+                while (!(ok = seg->go.load(std::memory_order_acquire) != 0) && std::chrono::steady_clock::now() < patience &&
+                       std::chrono::steady_clock::now() < deadline)
+                    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+            if (ok)
+            {
+                seg_ = seg;
+                return;
+            }
+            if (seg->magic.load(std::memory_order_acquire) == ShmSeg::kMagic)
+            {
+                // take the attachment back — unless the go-ahead arrived in between (rank 0 counts attachments)
+                uint32_t cur = seg->attached.load();
+                while (seg->go.load(std::memory_order_acquire) == 0 && !seg->attached.compare_exchange_weak(cur, cur - 1))
+                {
+                }
+                if (seg->go.load(std::memory_order_acquire) != 0)
+                {
+                    seg_ = seg;
+                    return;
+                }
+            }
+            munmap(seg, sizeof(ShmSeg));
+            std::this_thread::sleep_for(std::chrono::milliseconds(5));
         }
-        if (rank == 0)
-            (void)shm_unlink(name.c_str());
     }
     ~ShmComm() override
     {
@@ -226,7 +270,27 @@ class ShmComm final : public Comm
     ShmSeg *seg_ = nullptr;
     uint64_t calls_ = 0;
 };
+class EchoComm final : public Comm
+{
+  public:
+    EchoComm(int rank, int world)
+    {
+        if (world < 1 || rank < 0 || rank >= world)
+            throw std::runtime_error("EchoComm: bad rank / world size");
+        rank_ = rank, world_ = world;
+    }
+    void all_gather(const void *send, void *recv, size_t bytes) override
+    {
+        if (bytes == 0 || bytes > kMaxBytes)
+            throw std::runtime_error("EchoComm::all_gather: payload too large");
+        for (int q = 0; q < world_; ++q)
+            std::memcpy(static_cast<char *>(recv) + static_cast<size_t>(q) * bytes, send, bytes);
+    }
+    const char *transport() const override { return "echo"; }
+};
 } // namespace
+
+std::unique_ptr<Comm> make_echo_comm(int rank, int world) { return std::make_unique<EchoComm>(rank, world); }
 
 void rccl_unique_id(uint8_t *id)
 {

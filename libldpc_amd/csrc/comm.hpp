@@ -6,6 +6,7 @@
 //             `ldpcsim --devices`), exactly like ncclCommInitRank.
 //   ShmComm   a POSIX shared-memory segment on the host: rehearsals in which several ranks share one GPU (RCCL
 //             refuses two ranks on one device) and tests without a GPU.
+//   EchoComm  no transport at all: one process plays one rank of a world of any size (cost probes).
 //
 // The reference has no communication at all (OpenMP threads share counters, ldpcsim.cpp:175-252); what crosses
 // ranks here is what those shared counters carried, plus the accepted-pair counts that place every rank in the
@@ -46,5 +47,9 @@ void rccl_unique_id(uint8_t *id);
 std::unique_ptr<Comm> make_rccl_comm(int rank, int world, int device, const uint8_t *id);
 // name: shared-memory object name, the same on every rank and unique to the job (e.g. "/ldpc_amd_<port>")
 std::unique_ptr<Comm> make_shm_comm(int rank, int world, const std::string &name);
+// ONE process standing in for rank `rank` of `world`: all_gather answers every rank's slot with this rank's own payload
+// (every piece of a sharded step then holds as many pairs as this one).  For measuring what a rank of a world-sized job
+// costs on a single GPU (tools/shard_probe.py); results are frames of valid noise, not the frames of the real stream.
+std::unique_ptr<Comm> make_echo_comm(int rank, int world);
 
 } // namespace ldpc_amd

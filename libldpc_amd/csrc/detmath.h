@@ -498,6 +498,73 @@ DM_FN double dm_frac_lambda2(dm_frac f, dm_frac g)
 }
 
 /*
+ * Shared-reciprocal check nodes (likelihood-ratio form WITH early termination, check nodes of degree 3 and 4).
+ *
+ * Such a node divides three or four times, each time by a different denominator d_k, and a division is the most
+ * expensive thing the iteration does (a 16-cycle reciprocal estimate, two Newton steps, the quotient and its correction).
+ * Here the node takes ONE correctly rounded reciprocal r = 1 / P of the product P = d_0 d_1 .. d_{D-1} and recovers every
+ * 1 / d_k from it with multiplications (Montgomery's simultaneous inversion):
+ *
+ *     degree 3    p01 = d0 d1,  P = p01 d2,  r = 1/P
+ *                 i2 = r p01,   t = r d2,   i0 = t d1,   i1 = t d0                  lambda(c2v_k) = n_k i_k
+ *     degree 4    p01 = d0 d1,  p012 = p01 d2,  P = p012 d3,  r = 1/P
+ *                 i3 = r p012,  t = r d3,  i2 = t p01,  u = t d2,  i1 = u d0,  i0 = u d1
+ *
+ * with the numerators n_k and denominators d_k of dm_ratio_lambda (degree 3) and of the fraction form (degree 4: the two
+ * partial results F[1], B[2] stay undivided, dm_ratio_lambda_frac) formed exactly as before.  22 instructions and one
+ * reciprocal instead of 30 and three (degree 3), 32 and one instead of 44 and four (degree 4).  Every factor is positive
+ * and every operation is a plain binary64 multiply, so an output carries about three more roundings than a quotient would:
+ * a relative error of a few 1e-16 on a ratio, i.e. that much ABSOLUTE error on the message's LLR per iteration.
+ *
+ * Range.  Inputs lie in [2^-240, 2^240).  Degree 3: d = 1 + ab in [1, 2^481); degree 4: d in [2^-240, 2^723).  P never
+ * underflows (>= 2^-960) but may exceed the double range when several inputs are large at once; the node therefore returns
+ * the upper word of P and a frame in which any P reached 2^897 is treated like a frame that left the box: decoded again
+ * from scratch by the LLR-domain form.  The threshold is chosen so that the check rides on the escape tracking the form has
+ * anyway: (upper word of P) >> 2 reaches DM_RATIO_KEY_SPAN exactly when P >= 2^897 — infinities, NaNs and negative values
+ * included, positive doubles order like their bit patterns — so DM_SHARED_TRACK feeds the same running maximum as
+ * DM_RATIO_TRACK (one shift and one max per node, no register of its own; a per-node fall-back to separate quotients was
+ * measured first and costs the headline kernel its fifth resident frame: 12 bytes of scratch at 96 registers).  For
+ * P < 2^897 every intermediate lies within 2^-+1000 and dm_ratio_div(1, P) is the correctly rounded reciprocal on both
+ * sides.  The rule depends on the frame's own data only.  How often it fires (h.txt, AWGN): 0.05 % of the frames at -4 dB,
+ * 0.7 % at -2 dB, 6 % at 0 dB, half of them at +2 dB — far above the waterfall, where a frame takes two or three iterations.
+ * Frames decoded WITHOUT early termination (hand-over form) keep the separately divided outputs: their messages grow until
+ * the hand-over and would overflow P first.
+ */
+#define DM_SHARED_KEY(p_hi) ((uint32_t)(p_hi) >> 2)
+#define DM_SHARED_TRACK(acc, p_hi) ((acc) = (acc) > DM_SHARED_KEY(p_hi) ? (acc) : DM_SHARED_KEY(p_hi))
+#define DM_SHARED_OVERFLOW(p_hi) (DM_SHARED_KEY(p_hi) >= DM_RATIO_KEY_SPAN) /* P >= 2^897, or not a positive finite number */
+
+DM_FN uint32_t dm_cn3_shared(double *v) /* v[j] = rho(v2c_j) on entry, lambda(c2v_j) on return; returns the upper word of P */
+{
+    const double n0 = v[2] + v[1], d0 = DM_FMA(v[2], v[1], 1.0); /* B[1] = B[2] [+] v[1] */
+    const double n1 = v[0] + v[2], d1 = DM_FMA(v[0], v[2], 1.0); /* F[0] [+] B[2] */
+    const double n2 = v[0] + v[1], d2 = DM_FMA(v[0], v[1], 1.0); /* F[1] = F[0] [+] v[1] */
+    const double p01 = d0 * d1, P = p01 * d2;
+    const double r = dm_ratio_div(1.0, P);
+    const double i2 = r * p01, t = r * d2;
+    const double i0 = t * d1, i1 = t * d0;
+    v[0] = n0 * i0, v[1] = n1 * i1, v[2] = n2 * i2;
+    return (uint32_t)(dm_bits(P) >> 32);
+}
+
+DM_FN uint32_t dm_cn4_shared(double *v)
+{
+    const double nF = DM_FMA(v[0], v[1], 1.0), dF = v[0] + v[1]; /* F[1] = nF / dF */
+    const double nB = DM_FMA(v[3], v[2], 1.0), dB = v[3] + v[2]; /* B[2] = nB / dB */
+    const double n0 = DM_FMA(dB, v[1], nB), d0 = DM_FMA(nB, v[1], dB); /* B[1] = B[2] [+] v[1] */
+    const double n1 = DM_FMA(dB, v[0], nB), d1 = DM_FMA(nB, v[0], dB); /* F[0] [+] B[2] */
+    const double n2 = DM_FMA(dF, v[3], nF), d2 = DM_FMA(nF, v[3], dF); /* F[1] [+] B[3] */
+    const double n3 = DM_FMA(dF, v[2], nF), d3 = DM_FMA(nF, v[2], dF); /* F[2] = F[1] [+] v[2] */
+    const double p01 = d0 * d1, p012 = p01 * d2, P = p012 * d3;
+    const double r = dm_ratio_div(1.0, P);
+    const double i3 = r * p012, t = r * d3;
+    const double i2 = t * p01, u = t * d2;
+    const double i1 = u * d0, i0 = u * d1;
+    v[0] = n0 * i0, v[1] = n1 * i1, v[2] = n2 * i2, v[3] = n3 * i3;
+    return (uint32_t)(dm_bits(P) >> 32);
+}
+
+/*
  * Hand-over (sum-product WITHOUT early termination).  With the syndrome check off a frame keeps iterating after it has
  * converged and its LLRs grow until they leave the box the ratio form can hold; decoding such frames in the LLR domain
  * from the start would pay its exp/log cost for every iteration.  Instead every frame starts in the ratio form and is

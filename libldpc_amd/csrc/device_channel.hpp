@@ -45,12 +45,26 @@ __device__ __forceinline__ void channel_init(const DecodeArgs &a, uint64_t frame
             // element 0 = y*mult, element 1 = x*mult (libstdc++ returns y first and saves x; channel.cpp:62-68)
             const uint64_t g0 = a.normal_base + frame * static_cast<uint64_t>(nct);
             const uint64_t q_lo = g0 >> 1, q_hi = (g0 + nct - 1) >> 1;
+            // The noise generator leaves the accepted pairs in one slab per generator chunk (rng_kernels.hip): find the slab
+            // of the frame's first pair — a first guess from the expected pairs per slab, corrected on the table of
+            // cumulative counts (wave-uniform: scalar loads); a frame's pairs then lie in that slab or the ones after it.
+            const auto cum = uniform_table(a.slab_cum);
+            const uint64_t rel_lo = q_lo - a.pair_origin;
+            uint32_t j0 = static_cast<uint32_t>(static_cast<float>(rel_lo) * a.slab_pairs_inv);
+            j0 = j0 < a.n_slabs ? j0 : a.n_slabs - 1;
+            while (j0 > 0 && rel_lo < cum[j0])
+                --j0;
+            while (j0 + 1 < a.n_slabs && rel_lo >= cum[j0 + 1])
+                ++j0;
             for (uint64_t q = q_lo + tid; q <= q_hi; q += kThreads)
             {
-                // the noise-stream kernels (polar_compact_kernel) already turned the accepted trial into its normals
+                const uint64_t rel = q - a.pair_origin;
+                uint32_t j = j0;
+                while (j + 1 < a.n_slabs && rel >= a.slab_cum[j + 1])
+                    ++j;
                 // streamed once: non-temporal, so that the 8 KB of a frame do not push the slot tables — which every
                 // frame that starts on this CU reads — out of the CU's 32 KB vector cache
-                const uint64_t *pq = a.pairs + 2 * (q - a.pair_base);
+                const uint64_t *pq = a.pairs + static_cast<uint64_t>(j) * a.slab_words + 2 * (rel - a.slab_cum[j]);
                 ulonglong2 pp;
                 pp.x = __builtin_nontemporal_load(pq), pp.y = __builtin_nontemporal_load(pq + 1);
                 const double nrm[2] = {dm_from_bits(pp.x), dm_from_bits(pp.y)};

@@ -133,10 +133,22 @@ __device__ __forceinline__ void cn_core(double (&v)[D])
 // lambda(c2v_j) on return.  Partial results F[j], B[j] are carried as rho; the last box-plus of every output is
 // taken directly in lambda form, so a degree-3 node costs three divisions and a node of degree D >= 4 costs D (its
 // partial results stay undivided fractions).
-template <int D>
-__device__ __forceinline__ void cn_ratio(double (&v)[D])
+// SHARED (early-termination kernels): nodes of degree 3 and 4 take one reciprocal of the product of their denominators
+// (detmath.h, "Shared-reciprocal check nodes"); the product's range check joins the frame's escape tracking (escaped).
+template <int D, bool SHARED = false>
+__device__ __forceinline__ void cn_ratio(double (&v)[D], uint32_t *escaped = nullptr)
 {
-    if constexpr (D == 2)
+    if constexpr (SHARED && D == 3)
+    {
+        const uint32_t h = dm_cn3_shared(v);
+        DM_SHARED_TRACK(*escaped, h);
+    }
+    else if constexpr (SHARED && D == 4)
+    {
+        const uint32_t h = dm_cn4_shared(v);
+        DM_SHARED_TRACK(*escaped, h);
+    }
+    else if constexpr (D == 2)
     {
         const double a = dm_ratio_div(1.0, v[1]), b = dm_ratio_div(1.0, v[0]);
         v[0] = a, v[1] = b;

@@ -110,23 +110,6 @@ struct OutStage
     static constexpr size_t kPinnedLimit = 1 << 20;
 };
 
-// t^(J*2^m) mod phi, computed lazily once per process
-const Gf2Poly &jump_poly(unsigned m)
-{
-    static std::mutex mu;
-    static std::vector<Gf2Poly> polys;
-    std::lock_guard<std::mutex> lk(mu);
-    if (mt64_charpoly().empty())
-        throw std::runtime_error("mt19937_64 characteristic polynomial has unexpected degree");
-    while (polys.size() <= m)
-    {
-        if (polys.empty())
-            polys.push_back(mt64_pow_t(MtStream::kChunkWords));
-        else
-            polys.push_back(gf2_mulmod(polys.back(), polys.back()));
-    }
-    return polys[m];
-}
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -171,115 +154,97 @@ void *DeviceBuffer::reserve(size_t bytes)
 }
 
 // ---------------------------------------------------------------------------------------------
-void ChunkTable::ensure(uint64_t c_lo, uint64_t c_hi, std::vector<ChunkTableOp> &ops)
+MtDevice::MtDevice()
 {
-    if (c_hi - c_lo > kCap)
-        throw std::runtime_error("mt19937_64 stream request exceeds the chunk-state table");
-    if (!valid_ || c_lo < base_)
+    // 3360 blocks = 1 048 320 words = 8 MB of raw stream per chunk: the serial twist chain of a chunk hides under the decode
+    // kernel and a 65 536-frame batch needs 82 jump-ahead tasks.  LDPC_AMD_CHUNK_BLOCKS: experiments / tests of the chunk edges.
+    chunk_blocks_ = 3360;
+    if (const char *e = std::getenv("LDPC_AMD_CHUNK_BLOCKS"))
     {
-        ops.push_back({ChunkTableOp::kUploadWindow0, 0, 0});
-        base_ = 0;
-        ready_ = 1;
-        pow_ready_ = 1;
-        valid_ = true;
-    }
-    auto rebase = [&](uint64_t c) {
-        ops.push_back({ChunkTableOp::kRebase, static_cast<uint32_t>(c - base_), 0});
-        base_ = c;
-        ready_ = 1;
-        pow_ready_ = 1;
-    };
-    for (;;)
-    {
-        const uint64_t need = c_hi - base_;
-        if (need <= ready_)
-            return;
-        if (need > kCap)
-        {
-            if (c_lo - base_ < ready_)
-            {
-                rebase(c_lo);
-                continue;
-            }
-            if (pow_ready_ >= kCap) // far seek: stride forward by the table length
-            {
-                rebase(base_ + ready_ - 1);
-                continue;
-            }
-        }
-        // extend by doubling: rows [pow, 2*pow) = jump_{J*pow}(rows [0, pow))
-        unsigned m = 0;
-        while ((1u << m) < pow_ready_)
-            ++m;
-        ops.push_back({ChunkTableOp::kJump, pow_ready_, m});
-        pow_ready_ *= 2;
-        ready_ = std::max(ready_, pow_ready_);
+        const long v = std::strtol(e, nullptr, 10);
+        if (v >= 1 && v <= (1 << 20))
+            chunk_blocks_ = static_cast<uint32_t>(v);
     }
 }
 
-void ChunkTable::note_next_written(uint64_t c_hi)
+MtDevice::~MtDevice()
 {
-    if (c_hi - base_ == ready_ && ready_ <= kCap)
-        ++ready_; // the state that follows the last generated chunk came for free (row index ready_ <= kCap)
+    for (auto &p : polys_)
+        if (p.second)
+            (void)hipFree(p.second);
 }
 
-void MtStream::reset(uint64_t seed)
+void MtDevice::reset(uint64_t seed)
 {
     if (seeded_ && seed == seed_)
         return; // chunk states depend on the seed only; keep them
     seed_ = seed;
     seeded_ = true;
-    table_.invalidate();
+    ring_.invalidate();
+    strided_.invalidate();
 }
 
-void MtStream::ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream)
+// device copy of t^(312 * chunk_blocks * stride) mod phi, uploaded once per stream object and stride
+const uint64_t *MtDevice::device_poly(uint64_t stride, void *stream)
+{
+    for (auto &p : polys_)
+        if (p.first == stride)
+            return static_cast<const uint64_t *>(p.second);
+    const Gf2Poly &g = chunk_jump_poly(chunk_blocks_, stride);
+    std::vector<uint64_t> padded(kJumpPolyWords, 0);
+    std::copy(g.begin(), g.begin() + kMtWords, padded.begin());
+    void *d = nullptr;
+    check(hipMalloc(&d, sizeof(uint64_t) * kJumpPolyWords), "hipMalloc poly");
+    polys_.emplace_back(stride, d);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    check(hipMemcpyAsync(d, padded.data(), sizeof(uint64_t) * kJumpPolyWords, hipMemcpyHostToDevice, s), "upload poly");
+    check(hipStreamSynchronize(s), "sync"); // `padded` is a local buffer
+    return static_cast<const uint64_t *>(d);
+}
+
+void MtDevice::apply(const std::vector<StateOp> &ops, uint64_t *table, void *stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t row = sizeof(uint64_t) * kMtWords;
-    uint64_t *st = static_cast<uint64_t *>(states_.reserve(row * (kStateCap + 1)));
-    std::vector<ChunkTableOp> ops;
-    table_.ensure(c_lo, c_hi, ops);
-    for (const ChunkTableOp &op : ops)
+    for (const StateOp &op : ops)
         switch (op.kind)
         {
-        case ChunkTableOp::kUploadWindow0:
+        case StateOp::kUpload0:
         {
             uint64_t w0[kMtWords];
             mt64_window0(seed_, w0);
-            check(hipMemcpyAsync(st, w0, row, hipMemcpyHostToDevice, s), "upload window0");
+            check(hipMemcpyAsync(table + static_cast<size_t>(op.dst) * kMtWords, w0, row, hipMemcpyHostToDevice, s), "upload window0");
             check(hipStreamSynchronize(s), "sync"); // w0 is a stack buffer
             break;
         }
-        case ChunkTableOp::kRebase:
-            check(hipMemcpyAsync(st, st + static_cast<size_t>(op.a) * kMtWords, row, hipMemcpyDeviceToDevice, s), "rebase");
+        case StateOp::kCopy:
+            check(hipMemcpyAsync(table + static_cast<size_t>(op.dst) * kMtWords, table + static_cast<size_t>(op.src) * kMtWords, row,
+                                 hipMemcpyDeviceToDevice, s),
+                  "state copy");
             break;
-        case ChunkTableOp::kJump:
-            check(launch_mt_jump(st, st + static_cast<size_t>(op.a) * kMtWords, device_poly(op.b, stream), op.a, s), "mt_jump");
+        case StateOp::kJump:
+            check(launch_mt_jump(table, op.mod, op.src, op.dst, device_poly(op.stride, stream), op.n, s), "mt_jump");
+            jump_tasks_ += op.n;
             break;
         }
 }
 
-// device copy of t^(J*2^m) mod phi, uploaded once per stream object
-const uint64_t *MtStream::device_poly(unsigned m, void *stream)
+uint32_t MtDevice::ensure_ring(uint64_t c_lo, uint64_t c_hi, void *stream)
 {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    constexpr unsigned kMaxPolys = 16;
-    if (m >= kMaxPolys)
-        throw std::runtime_error("mt19937_64 jump distance out of range");
-    const size_t bytes = sizeof(uint64_t) * kJumpPolyWords;
-    uint64_t *base = static_cast<uint64_t *>(poly_.reserve(bytes * kMaxPolys));
-    while (polys_uploaded_ <= m)
-    {
-        const Gf2Poly &g = jump_poly(polys_uploaded_);
-        std::vector<uint64_t> padded(kJumpPolyWords, 0);
-        std::copy(g.begin(), g.begin() + kMtWords, padded.begin());
-        check(hipMemcpyAsync(base + static_cast<size_t>(polys_uploaded_) * kJumpPolyWords, padded.data(), bytes,
-                             hipMemcpyHostToDevice, s),
-              "upload poly");
-        check(hipStreamSynchronize(s), "sync"); // `padded` is a local buffer
-        ++polys_uploaded_;
-    }
-    return base + static_cast<size_t>(m) * kJumpPolyWords;
+    uint64_t *table = static_cast<uint64_t *>(ring_buf_.reserve(sizeof(uint64_t) * kMtWords * StateRing::kTotalRows));
+    std::vector<StateOp> ops;
+    ring_.ensure(c_lo, c_hi, ops);
+    apply(ops, table, stream);
+    return static_cast<uint32_t>(c_lo % StateRing::kRows);
+}
+
+uint64_t *MtDevice::ensure_strided(uint64_t first, uint32_t n, uint64_t stride, void *stream)
+{
+    uint64_t *table = static_cast<uint64_t *>(strided_buf_.reserve(sizeof(uint64_t) * kMtWords * (StridedTable::kMaxRows + 2)));
+    std::vector<StateOp> ops;
+    strided_.position(first, n, stride, ops);
+    apply(ops, table, stream);
+    return table;
 }
 
 const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream, int buffer)
@@ -287,32 +252,24 @@ const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (count == 0)
         count = 1;
-    const uint64_t c_lo = first / kChunkWords;
-    const uint64_t c_hi = (first + count + kChunkWords - 1) / kChunkWords;
-    ensure_states(c_lo, c_hi, stream);
+    const uint64_t cw = st.chunk_words();
+    const uint64_t c_lo = first / cw;
+    const uint64_t c_hi = (first + count + cw - 1) / cw;
+    if (c_hi - c_lo > StateRing::kWindow)
+        throw std::runtime_error("mt19937_64 stream request exceeds the chunk-state window");
+    const uint32_t row = st.ensure_ring(c_lo, c_hi, stream);
     const uint32_t n = static_cast<uint32_t>(c_hi - c_lo);
-    uint64_t *st = static_cast<uint64_t *>(states_.get());
-    uint64_t *raw = static_cast<uint64_t *>(raw_[buffer & 1].reserve(sizeof(uint64_t) * kChunkWords * n));
-    const uint64_t base = table_.base();
+    uint64_t *raw = static_cast<uint64_t *>(raw_[buffer & 1].reserve(sizeof(uint64_t) * cw * n));
+    uint32_t words = static_cast<uint32_t>(cw);
     if (n == 1)
     {
         // a short request inside one chunk (single frames, small batches): only the prefix of the chunk that is asked
-        // for is generated (whole twist rounds of 312 words); the state after the chunk is then not produced
-        const uint64_t need = (first + count - c_lo * kChunkWords + kMtWords - 1) / kMtWords * kMtWords;
-        if (need < kChunkWords)
-        {
-            check(launch_mt_generate(st + (c_lo - base) * kMtWords, nullptr, raw, 1, static_cast<uint32_t>(need), 1, s), "mt_generate");
-            return raw + (first - c_lo * kChunkWords);
-        }
+        // for is generated (whole twist rounds of 312 words)
+        const uint64_t need = (first + count - c_lo * cw + kMtWords - 1) / kMtWords * kMtWords;
+        words = static_cast<uint32_t>(std::min<uint64_t>(need, cw));
     }
-    // the state that follows the last chunk comes for free, when the table has a row for it (rows 0..kStateCap)
-    const int64_t nr = table_.next_row(c_hi);
-    uint64_t *next_last = nr >= 0 ? st + static_cast<size_t>(nr) * kMtWords : nullptr;
-    check(launch_mt_generate(st + (c_lo - base) * kMtWords, next_last, raw, n, static_cast<uint32_t>(kChunkWords), pack_, s),
-          "mt_generate");
-    if (next_last)
-        table_.note_next_written(c_hi);
-    return raw + (first - c_lo * kChunkWords);
+    check(launch_mt_generate(st.ring(), MtDevice::ring_rows(), row, raw, n, words, n == 1 ? 1 : pack_, s), "mt_generate");
+    return raw + (first - c_lo * cw);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -422,6 +379,13 @@ void Engine::prof_mark(int which, void *stream)
 // mean duration (ms) of the launches of kind `which` (0 decode kernel, 1 noise stream) since the previous call
 float Engine::last_ms(int which)
 {
+    if (which == 2 || which == 3)
+    {
+        const int k = which - 2;
+        const float v = host_n_[k] ? static_cast<float>(host_ms_[k] / static_cast<double>(host_n_[k])) : 0.f;
+        host_ms_[k] = 0, host_n_[k] = 0;
+        return v;
+    }
     bind_device();
     auto &q = prof_pending_[which ? 1 : 0];
     double sum = 0;
@@ -518,10 +482,14 @@ void Engine::synchronize(void *stream)
 // frames per launch: bounded so that the noise-stream buffers and the memory-resident workspace stay modest
 uint64_t Engine::max_sub_batch() const
 {
+    // the normals of a batch: at most kMaxSlabs chunk slabs (4 GB) per buffer
+    constexpr uint64_t kMaxSlabs = 476;
+    const uint64_t pairs_per_frame = std::max<uint64_t>(1, (static_cast<uint64_t>(plan_.nct) + 1) / 2 + 1);
+    const uint64_t by_noise = std::max<uint64_t>(1, (kMaxSlabs - 2) * noise_.st.chunk_trials() * 3 / 4 / pairs_per_frame);
     if (plan_.lds_ok || reg_plan_.ok)
-        return 1u << 17;
+        return std::min<uint64_t>(1u << 17, by_noise);
     const uint64_t per_frame = 8ull * plan_.nnz + 8ull * plan_.nc + plan_.nnz;
-    return std::max<uint64_t>(1, std::min<uint64_t>(1u << 17, (8ull << 30) / per_frame));
+    return std::max<uint64_t>(1, std::min<uint64_t>({1u << 17, (8ull << 30) / per_frame, by_noise}));
 }
 
 void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, uint64_t n, void *stream)
@@ -840,8 +808,9 @@ void Engine::stream_begin(int channel, uint64_t seed, double x, bool fresh)
     chan_ = channel;
     x_ = x;
     frame_pos_ = 0;
-    pair_next_ = 0;
     raw_next_ = 0;
+    cur_pair_ = cur_chunk_ = cur_k_ = 0;
+    sh_chunk_ = sh_pairs_ = 0;
     stream_mode_ = 0;
     noise_.reset(seed);
     if (fresh || info_.seed() != (seed << 1))
@@ -858,8 +827,6 @@ void Engine::stream_begin(int channel, uint64_t seed, double x, bool fresh)
     else
         delta_ = std::log((1 - x) / x); // channel.cpp:139
 }
-
-uint64_t Engine::stream_raw_draws() const { return raw_next_; }
 
 void Engine::ensure_rng_stream()
 {
@@ -902,74 +869,208 @@ void Engine::noise_raw_release(int buffer, void *stream)
     pairs_in_use_[buffer] = true;
 }
 
-// Locate the accepted polar pairs that supply the normals of frames [frame_pos_, frame_pos_+n).
-void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream)
+// One pass of the noise generator on the side stream: `full` whole chunks from `chunk` on (+ a prefix of last_blocks twist
+// blocks of the chunk after them) -> normals in the slabs of buffer `buf`, their counts, the slab table, and where the
+// consumer stands afterwards.  Chunk start states: the ring (one rank reading front to back) or the strided table (sharded).
+Engine::NoisePass Engine::noise_pass(uint64_t chunk, uint32_t full, uint32_t last_blocks, uint32_t n_piece, uint64_t need, uint64_t target,
+                                     int buf, bool write_normals, bool strided, uint64_t stride)
+{
+    hipStream_t s = static_cast<hipStream_t>(rng_stream_);
+    MtDevice &st = noise_.st;
+    NoisePass np;
+    np.n_slabs = full + (last_blocks ? 1 : 0);
+    if (np.n_slabs == 0)
+        throw std::runtime_error("noise generator: empty pass");
+    if (np.n_slabs > (strided ? StridedTable::kMaxRows : StateRing::kWindow))
+        throw std::runtime_error("noise generator: batch spans more chunks than the state table holds");
+    const uint64_t slab_words = 2 * st.chunk_trials();
+    NormalsArgs na{};
+    if (strided)
+    {
+        na.ring = st.ensure_strided(chunk, np.n_slabs, stride, s);
+        na.ring_rows = MtDevice::strided_rows();
+        na.first_row = 0;
+    }
+    else
+    {
+        na.first_row = st.ensure_ring(chunk, chunk + np.n_slabs, s);
+        na.ring = st.ring();
+        na.ring_rows = MtDevice::ring_rows();
+    }
+    np.slabs = write_normals ? static_cast<uint64_t *>(slabs_[buf].reserve(8 * slab_words * np.n_slabs)) : nullptr;
+    // (a counting pass must not touch the slab table a decode launch in flight may still read)
+    np.cum = static_cast<uint64_t *>((write_normals ? slab_cum_[buf] : nz_cum_skip_).reserve(8 * (static_cast<size_t>(np.n_slabs) + 1)));
+    uint32_t *counts = static_cast<uint32_t *>(nz_counts_.reserve(4 * static_cast<size_t>(np.n_slabs)));
+    NormalsResult *res = static_cast<NormalsResult *>(nz_result_.reserve(sizeof(NormalsResult)));
+    na.slabs = np.slabs;
+    na.slab_words = slab_words;
+    na.counts = counts;
+    na.write_normals = write_normals ? 1 : 0;
+    na.locate_chunk = 0xFFFFFFFFu;
+    na.pack = noise_.pack();
+    na.raw = static_cast<uint64_t *>(nz_raw_.reserve(8 * st.chunk_words() * std::max<uint32_t>(full, 1)));
+    na.lookback = static_cast<uint64_t *>(nz_lookback_.reserve(8 * normals_lookback_words(std::max<uint32_t>(full, 1), st.chunk_blocks())));
+    if (full)
+    {
+        na.n_chunks = full;
+        na.blocks = st.chunk_blocks();
+        check(launch_mt_normals(na, s), "mt_normals");
+    }
+    if (last_blocks)
+    {
+        NormalsArgs nl = na;
+        nl.first_row = (na.first_row + full) % na.ring_rows;
+        nl.n_chunks = 1;
+        nl.blocks = last_blocks;
+        nl.slabs = np.slabs ? np.slabs + slab_words * full : nullptr;
+        nl.counts = counts + full;
+        nl.pack = 1;
+        check(launch_mt_normals(nl, s), "mt_normals (prefix)");
+    }
+    check(launch_normals_finish(counts, np.n_slabs, n_piece, full, need, target, np.cum, res, s), "normals_finish");
+    check(hipMemcpyAsync(&np.res, res, sizeof np.res, hipMemcpyDeviceToHost, s), "noise result");
+    const auto t0 = std::chrono::steady_clock::now();
+    check(hipStreamSynchronize(s), "sync"); // waits for the noise-stream kernels only, not for the caller's decode
+    host_ms_[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ++host_n_[1];
+    return np;
+}
+
+void Engine::fill_slab_args(DecodeArgs &a, const NoisePass &np, uint64_t pair_origin, int buf) const
+{
+    a.pairs = np.slabs;
+    a.slab_cum = np.cum;
+    a.slab_words = 2 * noise_.st.chunk_trials();
+    a.n_slabs = np.n_slabs;
+    a.slab_pairs_inv = static_cast<float>(1.0 / (static_cast<double>(noise_.st.chunk_trials()) * 0.7853981633974483));
+    a.pair_origin = pair_origin;
+    a.sigma = sigma_, a.sigma2 = sigma2_;
+    a.shorten_llr = 99999.9; // channel.cpp:83
+    a.pairs_buffer = buf;
+}
+
+// The normals of frames [frame_pos_, frame_pos_ + n): normal g is element g & 1 of accepted pair g >> 1.
+void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream, bool write_normals)
 {
     hipStream_t user = static_cast<hipStream_t>(stream);
     ensure_rng_stream();
     hipStream_t s = static_cast<hipStream_t>(rng_stream_);
     const int buf = pp_;
-    pp_ ^= 1;
-    // the decode kernel that last read this pairs buffer (two batches ago) must be done before it is refilled
-    if (pairs_in_use_[buf])
-        check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev_pairs_free_[buf]), 0), "wait pairs free");
+    if (write_normals)
+    {
+        pp_ ^= 1;
+        // the decode kernel that last read this slab buffer (two batches ago) must be done before it is refilled
+        if (pairs_in_use_[buf])
+            check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev_pairs_free_[buf]), 0), "wait pairs free");
+    }
     const uint64_t nct = static_cast<uint64_t>(plan_.nct);
     const uint64_t g0 = frame_pos_ * nct, g1 = g0 + n * nct; // normals [g0, g1)
-    const uint64_t q_hi = (g1 - 1) >> 1;
-    const uint64_t want = q_hi + 1 - pair_next_;
-    // pairs[0] holds the carry pair (rank pair_next_-1), new pairs follow
-    uint64_t *pairs = static_cast<uint64_t *>(pairs_[buf].reserve(16 * (want + 1)));
-    uint64_t *carry = static_cast<uint64_t *>(carry_.reserve(16));
-    if (pair_next_ > 0)
-        check(hipMemcpyAsync(pairs, carry, 16, hipMemcpyDeviceToDevice, s), "carry in");
-    ScanResult *res = static_cast<ScanResult *>(scan_result_.reserve(sizeof(ScanResult)));
-    uint64_t trials = static_cast<uint64_t>(want * 1.2732395447351628 + 8.0 * std::sqrt(static_cast<double>(want)) + 256);
-    ScanResult h{};
+    const uint64_t q0 = g0 >> 1, q1 = (g1 - 1) >> 1, qn = g1 >> 1;
+    if (q0 != cur_pair_)
+        throw std::runtime_error("noise stream out of step");
+    // pairs that must exist from the start of chunk cur_chunk_ on / list index of the first pair the NEXT batch needs
+    const uint64_t need = cur_k_ + (q1 - q0 + 1), target = cur_k_ + (qn - q0);
+    const uint64_t ct = noise_.st.chunk_trials();
+    double trials = static_cast<double>(need) * 1.2732395447351628 + 8.0 * std::sqrt(static_cast<double>(need)) + 256;
+    NoisePass np;
     PhaseTrace tr;
     prof_mark(1, s);
     for (;;)
     {
-        const uint64_t *raw = noise_.generate(raw_next_, 2 * trials, s);
-        tr.mark("generate(enqueue)");
-        const uint32_t n_blocks = static_cast<uint32_t>((trials + kScanBlock - 1) / kScanBlock);
-        uint32_t *counts = static_cast<uint32_t *>(scan_counts_.reserve(4 * static_cast<size_t>(n_blocks)));
-        uint64_t *offs = static_cast<uint64_t *>(scan_offsets_.reserve(8 * static_cast<size_t>(n_blocks)));
-        check(launch_polar_scan(raw, trials, want, counts, offs, pairs + 2, res, s), "polar_scan");
-        check(hipMemcpyAsync(&h, res, sizeof h, hipMemcpyDeviceToHost, s), "scan result");
-        check(hipStreamSynchronize(s), "sync"); // waits for the noise-stream kernels only, not for the caller's decode
-        tr.mark("scan+sync");
-        if (h.enough)
+        const uint64_t t = static_cast<uint64_t>(trials);
+        uint64_t full = t / ct;
+        uint32_t last_blocks = static_cast<uint32_t>((t - full * ct + kBlockTrials - 1) / kBlockTrials);
+        if (last_blocks >= noise_.st.chunk_blocks())
+            ++full, last_blocks = 0;
+        np = noise_pass(cur_chunk_, static_cast<uint32_t>(full), last_blocks, static_cast<uint32_t>(full + (last_blocks ? 1 : 0)), need, target,
+                        buf, write_normals, false, 0);
+        tr.mark("noise pass");
+        if (np.res.enough)
             break;
         trials += trials / 8 + 4096; // vanishingly rare: take a longer look at the same stream
     }
     prof_mark(1, s);
-    check(hipMemcpyAsync(carry, pairs + 2 * want, 16, hipMemcpyDeviceToDevice, s), "carry out");
-    check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_ready_[buf]), s), "event");
-    check(hipStreamWaitEvent(user, static_cast<hipEvent_t>(ev_pairs_ready_[buf]), 0), "wait pairs ready");
-    a.pairs = pairs;
-    a.pair_base = pair_next_ - 1; // wraps to 2^64-1 for the very first batch: q - pair_base == q + 1
-    a.normal_base = g0;
-    a.sigma = sigma_, a.sigma2 = sigma2_;
-    a.shorten_llr = 99999.9; // channel.cpp:83
-    a.pairs_buffer = buf;
-    pair_next_ += want;
-    raw_next_ += 2 * h.trials_used;
+    if (write_normals)
+    {
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_ready_[buf]), s), "event");
+        check(hipStreamWaitEvent(user, static_cast<hipEvent_t>(ev_pairs_ready_[buf]), 0), "wait pairs ready");
+        fill_slab_args(a, np, q0 - cur_k_, buf);
+        a.normal_base = g0;
+    }
+    cur_chunk_ += np.res.next_slab;
+    cur_k_ = np.res.next_k;
+    cur_pair_ = qn;
+}
+
+// raw 64-bit draws consumed from the noise stream since stream_begin (what orc_chan_raw_draws counts)
+uint64_t Engine::stream_raw_draws()
+{
+    if (chan_ != kAwgn)
+        return raw_next_;
+    if (stream_mode_ == 2)
+        return sh_chunk_ * noise_.st.chunk_words();
+    const uint64_t nct = static_cast<uint64_t>(plan_.nct);
+    const uint64_t g1 = frame_pos_ * nct;
+    if (g1 == 0)
+        return 0;
+    // the last pair the stream has drawn: (g1 - 1) >> 1.  cur_* describe pair g1 >> 1: the same pair (its second normal is
+    // still saved) when g1 is odd, the pair before it otherwise — which may be the last accepted pair of the previous chunk.
+    bind_device();
+    ensure_rng_stream();
+    hipStream_t s = static_cast<hipStream_t>(rng_stream_);
+    uint64_t chunk = cur_chunk_;
+    uint32_t rank = static_cast<uint32_t>(cur_k_);
+    if ((g1 & 1) == 0)
+    {
+        if (cur_k_ > 0)
+            --rank;
+        else
+            --chunk, rank = 0xFFFFFFFFu;
+    }
+    MtDevice &st = noise_.st;
+    NormalsArgs na{};
+    na.first_row = st.ensure_ring(chunk, chunk + 1, s);
+    na.ring = st.ring();
+    na.ring_rows = MtDevice::ring_rows();
+    na.n_chunks = 1;
+    na.blocks = st.chunk_blocks();
+    na.slab_words = 2 * st.chunk_trials();
+    na.counts = static_cast<uint32_t *>(nz_counts_.reserve(4));
+    na.write_normals = 0;
+    na.locate_chunk = 0;
+    na.locate_rank = rank;
+    na.locate_out = static_cast<uint64_t *>(nz_locate_.reserve(8));
+    na.pack = 1;
+    na.raw = static_cast<uint64_t *>(nz_raw_.reserve(8 * st.chunk_words()));
+    na.lookback = static_cast<uint64_t *>(nz_lookback_.reserve(8 * normals_lookback_words(1, st.chunk_blocks())));
+    const uint64_t none = rank == 0xFFFFFFFFu ? 0 : ~0ull; // ("last pair": a running maximum over the chunk's workgroups)
+    uint64_t t = none;
+    check(hipMemcpyAsync(na.locate_out, &t, 8, hipMemcpyHostToDevice, s), "locate");
+    check(hipStreamSynchronize(s), "sync");
+    check(launch_mt_normals(na, s), "mt_normals (locate)");
+    check(hipMemcpyAsync(&t, na.locate_out, 8, hipMemcpyDeviceToHost, s), "locate");
+    check(hipStreamSynchronize(s), "sync");
+    if (rank != 0xFFFFFFFFu && t == none)
+        throw std::runtime_error("noise stream position not found");
+    return 2 * (chunk * st.chunk_trials() + t + 1);
 }
 
 void Engine::stream_skip(uint64_t n_frames, void *stream)
 {
     if (!chan_)
         throw std::runtime_error("stream_begin() has not been called");
+    if (stream_mode_ == 2)
+        throw std::runtime_error("stream_skip after stream_decode_sharded on the same stream: call stream_begin first");
+    stream_mode_ = 1;
     upload_plan();
     const uint64_t nct = static_cast<uint64_t>(plan_.nct);
     while (n_frames)
     {
-        const uint64_t n = std::min<uint64_t>(n_frames, 1u << 17);
+        const uint64_t n = std::min<uint64_t>(n_frames, max_sub_batch());
         encode_frames(n, false, stream);
         if (chan_ == kAwgn)
         {
             DecodeArgs a{};
-            awgn_prepare(n, a, stream);
+            awgn_prepare(n, a, stream, /*write_normals=*/false);
         }
         else
             raw_next_ += n * nct;
@@ -1035,10 +1136,40 @@ void Engine::stream_decode(const DecParams &p, uint64_t n_frames, const BatchOut
 }
 
 // ---------------------------------------------------------------------------------------------
-uint64_t Engine::shard_capacity(uint64_t target_frames, int world)
+// Geometry of a sharded AWGN step of about target_frames frames over `world` ranks: every rank's piece is `m` whole
+// generator chunks (so that its chunk start states are the previous step's advanced by ONE polynomial, world * m chunks),
+// followed by a margin of one frame's worth of trials from the next chunk.
+namespace
 {
-    const uint64_t per = (target_frames + world - 1) / world;
-    return per + per / 16 + 64; // the acceptance count of a piece varies by a few parts in a thousand
+struct ShardGeometry
+{
+    uint32_t m;             // chunks per piece
+    uint32_t margin_blocks; // twist blocks of the chunk after the piece that are generated as well
+};
+ShardGeometry shard_geometry(uint64_t target_frames, int world, uint64_t nct, uint64_t chunk_trials, uint32_t chunk_blocks)
+{
+    const double pairs_per_rank = static_cast<double>(std::max<uint64_t>(target_frames, 1)) * static_cast<double>(nct) / 2.0 / world;
+    const double chunks = pairs_per_rank * 1.2732395447351628 / static_cast<double>(chunk_trials);
+    ShardGeometry g;
+    g.m = static_cast<uint32_t>(std::clamp<double>(std::floor(chunks + 0.5), 1.0, static_cast<double>(StridedTable::kMaxRows - 1)));
+    // the pairs of one frame beyond the piece (the last frame a rank owns may end in its neighbour's piece): twice the
+    // expected trials plus 8192, in whole blocks
+    const uint64_t margin_trials = (nct / 2 + 2) * 2 + 8192;
+    g.margin_blocks = static_cast<uint32_t>(std::min<uint64_t>((margin_trials + kBlockTrials - 1) / kBlockTrials, chunk_blocks));
+    return g;
+}
+} // namespace
+
+uint64_t Engine::shard_capacity(uint64_t target_frames, int world) const
+{
+    world = std::max(world, 1);
+    const uint64_t nct = static_cast<uint64_t>(plan_.nct);
+    const uint64_t even = (std::max<uint64_t>(target_frames, 1) + world - 1) / world; // BSC / BEC: even split
+    // AWGN: a frame belongs to the rank whose piece holds its first pair; a piece of m chunks holds at most m * chunk_trials
+    // pairs (every trial accepted), i.e. at most that many / (nct / 2) frame starts — a bound, not a statistical estimate
+    const ShardGeometry g = shard_geometry(target_frames, world, nct, noise_.st.chunk_trials(), noise_.st.chunk_blocks());
+    const uint64_t awgn = (2 * static_cast<uint64_t>(g.m) * noise_.st.chunk_trials() + nct - 1) / nct + 2;
+    return std::max(even, awgn);
 }
 
 void Engine::encoder_snapshot(void *stream)
@@ -1077,86 +1208,92 @@ void Engine::encoder_restore_and_skip(uint64_t frames, void *stream)
 Engine::ShardStep Engine::stream_decode_sharded(Comm &comm, const DecParams &p, uint64_t target_frames, const BatchOut &out,
                                                 void *stream)
 {
+    // (argument errors: the same on every rank, thrown before anything is exchanged)
     if (!chan_)
         throw std::runtime_error("stream_begin() has not been called");
-    upload_plan();
     const int R = comm.world(), r = comm.rank();
     const uint64_t nct = static_cast<uint64_t>(plan_.nct), cap = shard_capacity(target_frames, R);
-    if (cap > max_sub_batch())
-        throw std::runtime_error("sharded step too large for one launch per rank");
     target_frames = std::max<uint64_t>(target_frames, 1);
     if (stream_mode_ == 1)
         throw std::runtime_error("stream_decode_sharded after stream_decode on the same stream: call stream_begin first");
     stream_mode_ = 2;
+    if (chan_ != kAwgn)
+        upload_plan();
     ShardStep st;
     st.step_first = frame_pos_;
     DecodeArgs a{};
     if (chan_ == kAwgn)
     {
-        ensure_rng_stream();
-        hipStream_t s = static_cast<hipStream_t>(rng_stream_), user = static_cast<hipStream_t>(stream);
-        const int buf = pp_;
-        pp_ ^= 1;
-        if (pairs_in_use_[buf])
-            check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev_pairs_free_[buf]), 0), "wait pairs free");
-        // the step: T trials of the raw stream, a multiple of R scan blocks, enough for about target_frames frames
-        const uint64_t want_pairs = (target_frames * nct + 1) / 2;
-        const uint64_t unit = static_cast<uint64_t>(R) * kScanBlock;
-        const uint64_t T = std::max<uint64_t>(unit, static_cast<uint64_t>(static_cast<double>(want_pairs) * 1.2732395447351628) / unit * unit);
-        const uint64_t piece = T / R;
-        // margin: the pairs of one frame beyond the piece (the last frame a rank owns may end in its neighbour's piece)
-        const uint64_t margin = ((nct / 2 + 2) * 2 + 4 * kScanBlock - 1) / kScanBlock * kScanBlock;
-        const uint64_t t0 = raw_next_ / 2 + static_cast<uint64_t>(r) * piece;
-        prof_mark(1, s);
-        const uint64_t *raw = noise_.generate(2 * t0, 2 * (piece + margin), s);
-        const uint32_t n_blocks = static_cast<uint32_t>((piece + margin) / kScanBlock);
-        uint32_t *counts = static_cast<uint32_t *>(scan_counts_.reserve(4 * static_cast<size_t>(n_blocks)));
-        uint64_t *offs = static_cast<uint64_t *>(scan_offsets_.reserve(8 * static_cast<size_t>(n_blocks)));
-        ScanResult *res = static_cast<ScanResult *>(scan_result_.reserve(2 * sizeof(ScanResult)));
-        check(launch_polar_count(raw, piece + margin, piece, counts, offs, res, res + 1, s), "polar_count");
-        ScanResult h[2];
-        check(hipMemcpyAsync(h, res, sizeof h, hipMemcpyDeviceToHost, s), "scan result");
-        check(hipStreamSynchronize(s), "sync");
-        // the exchange: every rank's accepted-pair count of its piece -> where each piece starts in the pair sequence
-        std::vector<uint64_t> acc(R);
-        const uint64_t mine = h[0].accepted;
-        comm.all_gather(&mine, acc.data(), sizeof mine);
-        std::vector<uint64_t> P(R + 1);
-        P[0] = pair_next_;
+        // The step: world * m whole chunks of the raw stream.  Rank r generates chunks [base + r m, base + (r+1) m) and the
+        // head of the next one, counts its accepted pairs, and ONE all-gather of {pairs in the piece, pairs incl. the
+        // margin, status} places every piece in the pair sequence.  Every rank can then evaluate every rank's conditions:
+        // a failure anywhere makes all ranks throw together instead of leaving the others in the next collective.
+        const ShardGeometry g = shard_geometry(target_frames, R, nct, noise_.st.chunk_trials(), noise_.st.chunk_blocks());
+        const uint64_t stride = static_cast<uint64_t>(R) * g.m;
+        uint64_t send[3] = {0, 0, 0};
+        NoisePass np;
+        std::string local_error;
+        int buf = -1;
+        try
+        {
+            if (cap > max_sub_batch())
+                throw std::runtime_error("sharded step too large for one launch per rank");
+            upload_plan(); // (the first touch of the GPU: a rank without a usable device fails here, inside the guarded part)
+            ensure_rng_stream();
+            hipStream_t s = static_cast<hipStream_t>(rng_stream_);
+            buf = pp_;
+            pp_ ^= 1;
+            if (pairs_in_use_[buf])
+                check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev_pairs_free_[buf]), 0), "wait pairs free");
+            prof_mark(1, s);
+            np = noise_pass(sh_chunk_ + static_cast<uint64_t>(r) * g.m, g.m, g.margin_blocks, g.m, 0, 0, buf, true, true, stride);
+            prof_mark(1, s);
+            send[0] = np.res.piece, send[1] = np.res.total;
+        }
+        catch (const std::exception &e)
+        {
+            local_error = e.what();
+            send[2] = 1;
+        }
+        std::vector<uint64_t> all(3 * static_cast<size_t>(R));
+        const auto t0 = std::chrono::steady_clock::now();
+        comm.all_gather(send, all.data(), sizeof send);
+        host_ms_[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ++host_n_[0];
         for (int q = 0; q < R; ++q)
-            P[q + 1] = P[q] + acc[q];
+            if (all[3 * static_cast<size_t>(q) + 2])
+                throw std::runtime_error(q == r ? "sharded step failed on this rank: " + local_error
+                                                : "sharded step failed on rank " + std::to_string(q));
+        std::vector<uint64_t> P(R + 1);
+        P[0] = sh_pairs_;
+        for (int q = 0; q < R; ++q)
+            P[q + 1] = P[q] + all[3 * static_cast<size_t>(q)];
         auto first_frame = [&](uint64_t pair) { return (2 * pair + nct - 1) / nct; }; // first frame whose first pair is >= pair
+        if (first_frame(P[0]) != frame_pos_)
+            throw std::runtime_error("sharded stream out of step");
+        for (int q = 0; q < R; ++q) // the same checks on every rank, for every rank
+        {
+            const uint64_t f0 = first_frame(P[q]), nq = first_frame(P[q + 1]) - f0;
+            if (nq > cap)
+                throw std::runtime_error("sharded step: more frames in a piece than the output buffers hold");
+            if (nq && ((f0 + nq) * nct - 1) / 2 - P[q] + 1 > all[3 * static_cast<size_t>(q) + 1])
+                throw std::runtime_error("sharded step: a frame extends beyond the margin generated after the piece");
+        }
         st.first = first_frame(P[r]);
         st.n = first_frame(P[r + 1]) - st.first;
         st.step_frames = first_frame(P[R]) - st.step_first;
-        if (first_frame(P[0]) != frame_pos_)
-            throw std::runtime_error("sharded stream out of step");
-        if (st.n > cap)
-            throw std::runtime_error("sharded step: more frames in a piece than the output buffers hold");
-        if (st.n)
-        {
-            const uint64_t last_pair = ((st.first + st.n) * nct - 1) >> 1;
-            const uint64_t need = last_pair - P[r] + 1;
-            if (need > h[1].accepted)
-                throw std::runtime_error("sharded step: a frame extends beyond the margin scanned after the piece");
-            uint64_t *pairs = static_cast<uint64_t *>(pairs_[buf].reserve(16 * (need + 1)));
-            check(launch_polar_compact(raw, piece + margin, offs, need, pairs, res, s), "polar_compact");
-            a.pairs = pairs;
-            a.pair_base = P[r];
-        }
-        prof_mark(1, s);
+        hipStream_t s = static_cast<hipStream_t>(rng_stream_), user = static_cast<hipStream_t>(stream);
         check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_ready_[buf]), s), "event");
         check(hipStreamWaitEvent(user, static_cast<hipEvent_t>(ev_pairs_ready_[buf]), 0), "wait pairs ready");
         a.mode = kModeAwgn;
+        fill_slab_args(a, np, P[r], buf);
         a.normal_base = st.first * nct;
-        a.sigma = sigma_, a.sigma2 = sigma2_;
-        a.shorten_llr = 99999.9; // channel.cpp:83
-        a.pairs_buffer = buf;
-        pair_next_ = P[R];
-        raw_next_ += 2 * T;
+        sh_pairs_ = P[R];
+        sh_chunk_ += stride;
     }
     else
     {
+        if (cap > max_sub_batch())
+            throw std::runtime_error("sharded step too large for one launch per rank");
         st.step_frames = target_frames;
         const uint64_t base = target_frames / R, extra = target_frames % R;
         st.n = base + (static_cast<uint64_t>(r) < extra ? 1 : 0);

@@ -15,6 +15,7 @@
 #include "comm.hpp"
 #include "kernels.hpp"
 #include "mt64.hpp"
+#include "mtstates.hpp"
 #include "plan.hpp"
 
 namespace ldpc_amd
@@ -61,42 +62,6 @@ class DeviceBuffer
     size_t size_ = 0;
 };
 
-// Bookkeeping of the chunk-start-state table of one stream (host only, no HIP calls: unit-testable without a GPU,
-// ldpc_hip_selftest_chunk_table).  Row r of the device table holds the generator state at the start of chunk
-// base()+r; rows [0, ready()) are valid; the table has kCap+1 rows (0..kCap).
-struct ChunkTableOp
-{
-    enum Kind
-    {
-        kUploadWindow0, // row 0 := state of chunk 0 (from the seed)
-        kRebase,        // row 0 := row a
-        kJump           // rows [a, 2a) := rows [0, a) advanced by a chunks (polynomial index b: a == 1 << b)
-    } kind;
-    uint32_t a, b;
-};
-
-class ChunkTable
-{
-  public:
-    static constexpr uint32_t kCap = 8192;
-    void invalidate() { valid_ = false; }
-    uint64_t base() const { return base_; }
-    uint32_t ready() const { return ready_; }
-    // append the operations that make the states of chunks [c_lo, c_hi) available as rows [c_lo-base, c_hi-base)
-    void ensure(uint64_t c_lo, uint64_t c_hi, std::vector<ChunkTableOp> &ops);
-    // row that may receive the state FOLLOWING chunk c_hi-1 when a generate launch over [c_lo, c_hi) produces it for
-    // free, or -1 when the table has no row for it
-    int64_t next_row(uint64_t c_hi) const { return c_hi - base_ <= kCap ? static_cast<int64_t>(c_hi - base_) : -1; }
-    // the launch wrote next_row(c_hi)
-    void note_next_written(uint64_t c_hi);
-
-  private:
-    bool valid_ = false;
-    uint64_t base_ = 0;      // chunk id of row 0
-    uint32_t ready_ = 0;     // rows [0, ready_) hold chunk start states
-    uint32_t pow_ready_ = 0; // power-of-two prefix obtained by doubling
-};
-
 // page-locked host memory for small transfers (single-frame decode(): the copies are latency, not bandwidth)
 class PinnedBuffer
 {
@@ -111,29 +76,59 @@ class PinnedBuffer
     size_t size_ = 0;
 };
 
-// One mt19937_64(seed) stream: chunk start states by jump-ahead, raw words generated on demand.
+// The chunk start states of one mt19937_64(seed) stream on the device: executes the operations mtstates.hpp plans
+// (uploads, copies, jump launches) and keeps the device copies of the jump polynomials.
+class MtDevice
+{
+  public:
+    MtDevice();
+    ~MtDevice();
+    MtDevice(const MtDevice &) = delete;
+    MtDevice &operator=(const MtDevice &) = delete;
+    void reset(uint64_t seed); // chunk states depend on the seed only: kept when it does not change
+    uint64_t seed() const { return seed_; }
+    uint32_t chunk_blocks() const { return chunk_blocks_; }
+    uint64_t chunk_words() const { return static_cast<uint64_t>(kMtWords) * chunk_blocks_; }
+    uint64_t chunk_trials() const { return chunk_words() / 2; }
+    // consecutive chunks [c_lo, c_hi): their start states in the ring; returns the ring row of c_lo
+    uint32_t ensure_ring(uint64_t c_lo, uint64_t c_hi, void *stream);
+    uint64_t *ring() const { return static_cast<uint64_t *>(ring_buf_.get()); }
+    static constexpr uint32_t ring_rows() { return StateRing::kRows; }
+    // sharded stream: rows 0 .. n-1 = chunks [first, first + n), consecutive calls `stride` chunks apart cost one launch
+    uint64_t *ensure_strided(uint64_t first, uint32_t n, uint64_t stride, void *stream);
+    static constexpr uint32_t strided_rows() { return StridedTable::kMaxRows + 2; }
+    uint64_t jump_tasks() const { return jump_tasks_; } // jump-ahead tasks launched so far (tools/shard_probe.py)
+
+  private:
+    void apply(const std::vector<StateOp> &ops, uint64_t *table, void *stream);
+    const uint64_t *device_poly(uint64_t stride, void *stream);
+    uint64_t seed_ = 0;
+    bool seeded_ = false;
+    uint32_t chunk_blocks_;
+    StateRing ring_;
+    StridedTable strided_;
+    DeviceBuffer ring_buf_, strided_buf_;
+    std::vector<std::pair<uint64_t, void *>> polys_; // (stride in chunks, device copy)
+    uint64_t jump_tasks_ = 0;
+};
+
+// Raw words of one mt19937_64(seed) stream (BSC / BEC draws, info words, ldpc_hip_mt64).
 class MtStream
 {
   public:
-    static constexpr uint64_t kChunkWords = 3360 * kMtWords; // 1048320 words = 8 MB per chunk
-    static constexpr uint32_t kStateCap = ChunkTable::kCap;
-    void reset(uint64_t seed);
-    uint64_t seed() const { return seed_; }
+    void reset(uint64_t seed) { st.reset(seed); }
+    uint64_t seed() const { return st.seed(); }
     // chunks per generator workgroup (1 or 4, kernels.hpp launch_mt_generate)
     void set_pack(int chunks_per_workgroup) { pack_ = chunks_per_workgroup; }
-    // Generate raw outputs [first, first+count) of the stream; returns a device pointer to word `first`.
-    // raw words [first, first + count) on `stream`, into one of the stream object's two output buffers
+    int pack() const { return pack_; }
+    // raw words [first, first + count) on `stream`, into one of the stream object's two output buffers; returns a device
+    // pointer to word `first`
     const uint64_t *generate(uint64_t first, uint64_t count, void *stream, int buffer = 0);
+    MtDevice st;
 
   private:
-    void ensure_states(uint64_t c_lo, uint64_t c_hi, void *stream);
-    const uint64_t *device_poly(unsigned m, void *stream);
-    uint64_t seed_ = 0;
     int pack_ = 1;
-    bool seeded_ = false;
-    ChunkTable table_;
-    unsigned polys_uploaded_ = 0;
-    DeviceBuffer states_, raw_[2], poly_;
+    DeviceBuffer raw_[2];
 };
 
 class Engine
@@ -177,21 +172,24 @@ class Engine
         uint64_t step_first = 0, step_frames = 0; // the global step
         uint64_t first = 0, n = 0;                // this rank's frames [first, first + n)
     };
-    static uint64_t shard_capacity(uint64_t target_frames, int world);
     ShardStep stream_decode_sharded(Comm &comm, const DecParams &p, uint64_t target_frames, const BatchOut &out, void *stream);
     // encoder state (info-word stream position + accumulated codeword) saved before a step / put back and advanced by
     // `frames` frames: how every rank lands on the state after the frame at which the simulation stopped
     void encoder_snapshot(void *stream);
     void encoder_restore_and_skip(uint64_t frames, void *stream);
     uint64_t stream_frame() const { return frame_pos_; }
-    uint64_t stream_raw_draws() const;
+    uint64_t stream_raw_draws(); // (AWGN: locates the last consumed trial with one generator pass over its chunk)
+    // frames a sharded step of about target_frames can put on one rank (the output buffers' size)
+    uint64_t shard_capacity(uint64_t target_frames, int world) const;
+    uint64_t noise_jump_tasks() const { return noise_.st.jump_tasks(); }
 
     void synchronize(void *stream);
     uint64_t max_sub_batch() const; // frames one launch takes; larger requests are split
 
     // kernel timing with HIP events on the launch stream (bench.py's roofline figure)
     void set_profiling(bool on);
-    // elapsed ms of the last batch: which = 0 decode kernel, 1 noise-stream kernels (generate + scan)
+    // mean ms since the previous call: which = 0 decode launches, 1 noise-stream kernels (HIP events); 2 host time inside the
+    // ranks' exchange, 3 host time waiting for the noise stream's result (wall clock)
     float last_ms(int which);
 
   private:
@@ -205,7 +203,18 @@ class Engine
     void upload_plan();
     void run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, uint64_t n, void *stream);
     void run_bec(const DecParams &p, const BatchOut &out, uint64_t n, const uint8_t *codeword, void *stream);
-    void awgn_prepare(uint64_t n_frames, DecodeArgs &a, void *stream);
+    // normals of frames [frame_pos_, frame_pos_ + n): generate, count, place (write_normals false: count only, stream_skip)
+    void awgn_prepare(uint64_t n_frames, DecodeArgs &a, void *stream, bool write_normals = true);
+    // one generator pass over chunks [chunk, chunk + full) (+ a prefix of `last_blocks` blocks of the next one) on the side stream
+    struct NoisePass
+    {
+        uint32_t n_slabs = 0;
+        uint64_t *slabs = nullptr, *cum = nullptr;
+        NormalsResult res{};
+    };
+    NoisePass noise_pass(uint64_t chunk, uint32_t full, uint32_t last_blocks, uint32_t n_piece, uint64_t need, uint64_t target, int buf,
+                         bool write_normals, bool strided, uint64_t stride);
+    void fill_slab_args(DecodeArgs &a, const NoisePass &np, uint64_t pair_origin, int buf) const;
     // advance the encoder by n frames; returns the per-frame codewords [n][nc] (nullptr when no G is
     // loaded, or when want_codewords is false)
     const uint8_t *encode_frames(uint64_t n, bool want_codewords, void *stream);
@@ -226,17 +235,21 @@ class Engine
     double x_ = 0, sigma2_ = 0, sigma_ = 0, delta_ = 0;
     uint64_t frame_pos_ = 0;
     int stream_mode_ = 0; // 0 fresh, 1 stream_decode / stream_skip, 2 stream_decode_sharded (pair bookkeeping differs)
-    uint64_t pair_next_ = 0; // accepted polar pairs located so far
-    uint64_t raw_next_ = 0;  // raw draws consumed so far (AWGN: where the next trial starts)
+    uint64_t raw_next_ = 0;  // BSC / BEC: raw draws consumed so far
+    // AWGN, one rank reading the stream front to back: the pair with stream index cur_pair_ (= first normal of the next
+    // frame >> 1) is the cur_k_-th accepted pair of chunk cur_chunk_
+    uint64_t cur_pair_ = 0, cur_chunk_ = 0, cur_k_ = 0;
+    // AWGN, sharded: the next step starts at chunk sh_chunk_, sh_pairs_ pairs were accepted before it
+    uint64_t sh_chunk_ = 0, sh_pairs_ = 0;
     MtStream noise_, info_;
     uint64_t info_pos_ = 0;     // info-word draws consumed (kc per frame)
     bool cw_run_valid_ = false; // cw_run_ holds the accumulated codeword
     DeviceBuffer cw_run_, cw_next_, cw_frames_, cw_before_, enc_prefix_;
     uint64_t last_enc_n_ = 0;   // frames of the last encode_frames call that produced cw_frames_
     const uint32_t *g_col_ptr_ = nullptr, *g_col_row_ = nullptr;
-    DeviceBuffer pairs_[2], carry_, scan_counts_, scan_offsets_, scan_result_;
-    // the AWGN noise-stream kernels run on their own stream so that the pairs of batch s+1 are located while
-    // the decode kernel of batch s drains; pairs_ is double-buffered, events order the two streams
+    DeviceBuffer slabs_[2], slab_cum_[2], nz_counts_, nz_result_, nz_locate_, nz_cum_skip_, nz_raw_, nz_lookback_;
+    // the AWGN noise generator runs on its own stream so that the normals of batch s+1 are produced while
+    // the decode kernel of batch s drains; the slabs are double-buffered, events order the two streams
     void *rng_stream_ = nullptr;
     void *ev_pairs_ready_[2] = {nullptr, nullptr}, *ev_pairs_free_[2] = {nullptr, nullptr};
     bool pairs_in_use_[2] = {false, false};
@@ -250,6 +263,8 @@ class Engine
     bool enc_snap_valid_ = false;
     DeviceBuffer redo_; // [0] = count, [1..] = frames handed back by the ratio-form launch
     bool profiling_ = false;
+    double host_ms_[2] = {0, 0}; // [0] exchange, [1] noise-stream wait
+    uint64_t host_n_[2] = {0, 0};
     std::vector<void *> prof_pending_[2], prof_free_; // hipEvent_t: begin/end pairs per launch, spare events
     void prof_mark(int which, void *stream);
 };

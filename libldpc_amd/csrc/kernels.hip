@@ -300,8 +300,10 @@ __device__ __forceinline__ double with_sign(double mag, uint32_t sign_hi) // mag
     return dm_from_bits(dm_bits(mag) | (static_cast<uint64_t>(sign_hi) << 32));
 }
 
-template <int D>
-__device__ __forceinline__ uint32_t cn_update_ratio(double *m, int stride)
+// SH: the shared-reciprocal form of degree-3 and degree-4 nodes (detmath.h); esc = the frame's escape tracking, which the
+// nodes' denominator products join
+template <int D, bool SH>
+__device__ __forceinline__ uint32_t cn_update_ratio(double *m, int stride, uint32_t &esc)
 {
     double v[D];
     uint32_t sg[D], par = 0;
@@ -313,25 +315,25 @@ __device__ __forceinline__ uint32_t cn_update_ratio(double *m, int stride)
         par ^= sg[j];
         v[j] = __builtin_fabs(x);
     }
-    cn_ratio<D>(v);
+    cn_ratio<D, SH>(v, &esc);
 #pragma unroll
     for (int j = 0; j < D; ++j)
         m[j * stride] = with_sign(v[j], sg[j]);
     return par;
 }
 
-template <int MAXD>
-__device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b, int lane);
-template <int MAXD>
-__device__ __forceinline__ uint32_t cn_block_ratio_fwd(double *msg, const CnBlock b, int lane)
+template <int MAXD, bool SH>
+__device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b, int lane, uint32_t &esc);
+template <int MAXD, bool SH>
+__device__ __forceinline__ uint32_t cn_block_ratio_fwd(double *msg, const CnBlock b, int lane, uint32_t &esc)
 {
-    return cn_block_ratio<MAXD>(msg, b, lane);
+    return cn_block_ratio<MAXD, SH>(msg, b, lane, esc);
 }
 
 // two full blocks (64 nodes each) of the same degree at once: two independent chains per lane hide the latency of
 // the divisions and of the LDS round trip; the constant stride lets the loads pair up (ds_read2st64_b64)
-template <int D0, int D1>
-__device__ __forceinline__ uint32_t cn_update_ratio2(double *m0, double *m1)
+template <int D0, int D1, bool SH>
+__device__ __forceinline__ uint32_t cn_update_ratio2(double *m0, double *m1, uint32_t &esc)
 {
     double v0[D0], v1[D1];
     uint32_t g0[D0], g1[D1], par0 = 0, par1 = 0;
@@ -351,8 +353,8 @@ __device__ __forceinline__ uint32_t cn_update_ratio2(double *m0, double *m1)
         par1 ^= g1[j];
         v1[j] = __builtin_fabs(x1);
     }
-    cn_ratio<D0>(v0);
-    cn_ratio<D1>(v1);
+    cn_ratio<D0, SH>(v0, &esc);
+    cn_ratio<D1, SH>(v1, &esc);
 #pragma unroll
     for (int j = 0; j < D0; ++j)
         m0[j * kWaveSize] = with_sign(v0[j], g0[j]);
@@ -362,41 +364,41 @@ __device__ __forceinline__ uint32_t cn_update_ratio2(double *m0, double *m1)
     return par0 | par1;
 }
 
-template <int MAXD>
-__device__ __forceinline__ uint32_t cn_pair_ratio(double *msg, uint32_t off0, uint32_t off1, int deg0, int deg1, int lane)
+template <int MAXD, bool SH>
+__device__ __forceinline__ uint32_t cn_pair_ratio(double *msg, uint32_t off0, uint32_t off1, int deg0, int deg1, int lane, uint32_t &esc)
 {
     double *m0 = msg + off0 + lane, *m1 = msg + off1 + lane;
     if (deg0 == deg1)
     {
         switch (deg0) // wave-uniform
         {
-        case 2: return cn_update_ratio2<2, 2>(m0, m1);
-        case 3: return cn_update_ratio2<3, 3>(m0, m1);
-        case 4: return cn_update_ratio2<4, 4>(m0, m1);
+        case 2: return cn_update_ratio2<2, 2, SH>(m0, m1, esc);
+        case 3: return cn_update_ratio2<3, 3, SH>(m0, m1, esc);
+        case 4: return cn_update_ratio2<4, 4, SH>(m0, m1, esc);
         default: break;
         }
         if constexpr (MAXD > 4)
             switch (deg0)
             {
-            case 5: return cn_update_ratio2<5, 5>(m0, m1);
-            case 6: return cn_update_ratio2<6, 6>(m0, m1);
-            case 7: return cn_update_ratio2<7, 7>(m0, m1);
-            case 8: return cn_update_ratio2<8, 8>(m0, m1);
+            case 5: return cn_update_ratio2<5, 5, SH>(m0, m1, esc);
+            case 6: return cn_update_ratio2<6, 6, SH>(m0, m1, esc);
+            case 7: return cn_update_ratio2<7, 7, SH>(m0, m1, esc);
+            case 8: return cn_update_ratio2<8, 8, SH>(m0, m1, esc);
             default: break;
             }
     }
     else if (deg0 == 4 && deg1 == 3) // each wave's list is in descending degree order (plan.cpp): every separate
-        return cn_update_ratio2<4, 3>(m0, m1); // chain costs the wave an LDS + division latency (~400 cycles)
+        return cn_update_ratio2<4, 3, SH>(m0, m1, esc); // chain costs the wave an LDS + division latency (~400 cycles)
     else if (deg0 == 3 && deg1 == 2)
-        return cn_update_ratio2<3, 2>(m0, m1);
+        return cn_update_ratio2<3, 2, SH>(m0, m1, esc);
     // anything else: one after the other
-    return cn_block_ratio_fwd<MAXD>(msg, CnBlock{off0, kWaveSize, static_cast<uint16_t>(deg0)}, lane) |
-           cn_block_ratio_fwd<MAXD>(msg, CnBlock{off1, kWaveSize, static_cast<uint16_t>(deg1)}, lane);
+    return cn_block_ratio_fwd<MAXD, SH>(msg, CnBlock{off0, kWaveSize, static_cast<uint16_t>(deg0)}, lane, esc) |
+           cn_block_ratio_fwd<MAXD, SH>(msg, CnBlock{off1, kWaveSize, static_cast<uint16_t>(deg1)}, lane, esc);
 }
 
 // returns the parity (bit 31) of the hard decisions on this lane's check node
-template <int MAXD>
-__device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b, int lane)
+template <int MAXD, bool SH>
+__device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b, int lane, uint32_t &esc)
 {
     if (lane >= b.count)
         return 0;
@@ -404,31 +406,31 @@ __device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b,
     const int s = b.count;
     switch (b.degree) // wave-uniform
     {
-    case 2: return cn_update_ratio<2>(m, s);
-    case 3: return cn_update_ratio<3>(m, s);
-    case 4: return cn_update_ratio<4>(m, s);
+    case 2: return cn_update_ratio<2, SH>(m, s, esc);
+    case 3: return cn_update_ratio<3, SH>(m, s, esc);
+    case 4: return cn_update_ratio<4, SH>(m, s, esc);
     default: break;
     }
     if constexpr (MAXD > 4)
         switch (b.degree)
         {
-        case 5: return cn_update_ratio<5>(m, s);
-        case 6: return cn_update_ratio<6>(m, s);
-        case 7: return cn_update_ratio<7>(m, s);
-        case 8: return cn_update_ratio<8>(m, s);
+        case 5: return cn_update_ratio<5, SH>(m, s, esc);
+        case 6: return cn_update_ratio<6, SH>(m, s, esc);
+        case 7: return cn_update_ratio<7, SH>(m, s, esc);
+        case 8: return cn_update_ratio<8, SH>(m, s, esc);
         default: break;
         }
     if constexpr (MAXD > 8)
         switch (b.degree)
         {
-        case 9: return cn_update_ratio<9>(m, s);
-        case 10: return cn_update_ratio<10>(m, s);
-        case 11: return cn_update_ratio<11>(m, s);
-        case 12: return cn_update_ratio<12>(m, s);
-        case 13: return cn_update_ratio<13>(m, s);
-        case 14: return cn_update_ratio<14>(m, s);
-        case 15: return cn_update_ratio<15>(m, s);
-        case 16: return cn_update_ratio<16>(m, s);
+        case 9: return cn_update_ratio<9, SH>(m, s, esc);
+        case 10: return cn_update_ratio<10, SH>(m, s, esc);
+        case 11: return cn_update_ratio<11, SH>(m, s, esc);
+        case 12: return cn_update_ratio<12, SH>(m, s, esc);
+        case 13: return cn_update_ratio<13, SH>(m, s, esc);
+        case 14: return cn_update_ratio<14, SH>(m, s, esc);
+        case 15: return cn_update_ratio<15, SH>(m, s, esc);
+        case 16: return cn_update_ratio<16, SH>(m, s, esc);
         default: break;
         }
     return 0;
@@ -1013,6 +1015,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         {
             PHASE_START
             uint32_t bad = 0;
+            constexpr bool SH = !HANDOVER; // early termination: shared-reciprocal check nodes (detmath.h)
             // blocks two at a time where they match (plan.cpp deals each wave's blocks in degree order); both
             // descriptors arrive with one scalar load (plan.cpp, cn_work_desc)
             for (int w = 0; w < P.cn_work_stride; w += 2)
@@ -1024,13 +1027,13 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     break;
                 if (b1.count == 0)
                 {
-                    bad |= cn_block_ratio<MAXD>(msg, b0, lane);
+                    bad |= cn_block_ratio<MAXD, SH>(msg, b0, lane, escaped);
                     break;
                 }
                 if (b0.count == kWaveSize && b1.count == kWaveSize)
-                    bad |= cn_pair_ratio<MAXD>(msg, b0.off, b1.off, b0.degree, b1.degree, lane);
+                    bad |= cn_pair_ratio<MAXD, SH>(msg, b0.off, b1.off, b0.degree, b1.degree, lane, escaped);
                 else
-                    bad |= cn_block_ratio<MAXD>(msg, b0, lane) | cn_block_ratio<MAXD>(msg, b1, lane);
+                    bad |= cn_block_ratio<MAXD, SH>(msg, b0, lane, escaped) | cn_block_ratio<MAXD, SH>(msg, b1, lane, escaped);
             }
             const int ph = I & 1;
             int wave_vote = (__ballot(bad != 0) != 0) | ((__ballot(DM_RATIO_ESCAPED(escaped)) != 0) << 1);

@@ -48,12 +48,19 @@ struct DecodeArgs
     uint64_t n_frames;
     // kModeLlr
     const double *llr_in; // [n_frames][nc], column order
-    // kModeAwgn: the two normals (bit patterns of y*mult, x*mult) of every accepted polar pair of the stream; pair q of the
-    // stream sits at pairs[2*(q - pair_base)], normal g = frame*nct + i comes from pair g>>1.
+    // kModeAwgn: the two normals (bit patterns of y*mult, x*mult) of every accepted polar pair of the stream, as the noise
+    // generator left them: one SLAB per generator chunk, compacted inside the slab in stream order (rng_kernels.hip,
+    // mt_normals_kernel).  slab_cum[j] = pairs in the slabs before j (slab_cum[0] = 0, n_slabs + 1 entries); the pair with
+    // stream index q sits in the slab j with slab_cum[j] <= q - pair_origin < slab_cum[j+1], at
+    // pairs[j * slab_words + 2 * (q - pair_origin - slab_cum[j])].  Normal g = frame*nct + i comes from pair g>>1.
     const uint64_t *pairs;
-    uint64_t pair_base;
-    uint64_t normal_base; // index of this batch's first normal in the stream
-    int pairs_buffer;     // host bookkeeping: which of the engine's two pairs buffers `pairs` points into
+    const uint64_t *slab_cum;
+    uint64_t slab_words;      // 64-bit words per slab (2 x the pairs a chunk can hold)
+    uint32_t n_slabs;
+    float slab_pairs_inv;     // 1 / (expected pairs per slab): first guess of the slab of a frame
+    uint64_t pair_origin;     // stream index of the first pair of slab 0
+    uint64_t normal_base;     // index of this batch's first normal in the stream
+    int pairs_buffer;         // host bookkeeping: which of the engine's two slab buffers `pairs` points into
     double sigma, sigma2; // sqrt(sigma2), sigma2 = 10^(-snr/10)
     double shorten_llr;   // 99999.9 (AWGN) or delta (BSC)
     // kModeBsc: raw draws, one per transmitted bit: raw[frame*nct + i]
@@ -155,39 +162,66 @@ int launch_bec(const BecArgs &a, void *stream);
 
 // ---- mt19937_64 on the device ----
 constexpr int kMtN = 312;
-// Generate chunk_words raw (tempered) outputs per chunk: chunk c starts from states[c*312..] and
-// writes out[c*chunk_words ..]; the state that follows the LAST chunk is written to next_last[0..312)
-// (may be null).  chunks_per_workgroup: 1, or 4 to keep the generator on a quarter of the compute units (for decode
-// kernels that own a whole CU per frame).
-int launch_mt_generate(const uint64_t *states, uint64_t *next_last, uint64_t *out, uint32_t n_chunks,
-                       uint32_t chunk_words, int chunks_per_workgroup, void *stream);
-// Jump: for task t, dst_states[t] = src_states[t] advanced by the polynomial `poly` (19937 coefficient
-// bits, kJumpPolyWords words: 312 + zero padding).
-int launch_mt_jump(const uint64_t *src_states, uint64_t *dst_states, const uint64_t *poly, uint32_t n_tasks,
-                   void *stream);
+constexpr uint32_t kBlockTrials = kMtN / 2; // one twist block of 312 words = 156 polar trials
+// Chunk start states live in a RING of ring_rows rows of 312 words: chunk i of a launch starts from row
+// (first_row + i) % ring_rows (first_row < ring_rows, n <= ring_rows).
+// Raw (tempered) outputs: chunk i writes out[i * chunk_words ..), chunk_words a multiple of 312.  pack: chunks per
+// workgroup (1, or 4 to keep the generator on a quarter of the compute units beside decode kernels that own a whole CU).
+int launch_mt_generate(const uint64_t *ring, uint32_t ring_rows, uint32_t first_row, uint64_t *out, uint32_t n_chunks,
+                       uint32_t chunk_words, int pack, void *stream);
+// Jump: row (dst_first + t) % ring_rows = row (src_first + t) % ring_rows advanced by the polynomial `poly` (19937
+// coefficient bits, kJumpPolyWords words: 312 + zero padding), t < n_tasks.  A task reads its source row before it writes,
+// so src_first == dst_first (in place) is allowed; otherwise the two row ranges must not overlap.
+int launch_mt_jump(uint64_t *ring, uint32_t ring_rows, uint32_t src_first, uint32_t dst_first, const uint64_t *poly,
+                   uint32_t n_tasks, void *stream);
 constexpr uint32_t kJumpPolyWords = 320;
 
-// Polar-method acceptance scan over trials (raw[2t], raw[2t+1]):
-//   pass 1: block_counts[b] = accepted trials in block b (kScanBlock trials per block)
-//   pass 2 (after an exclusive scan of block_counts): compact accepted pairs into pairs_out
-struct ScanResult
+// The AWGN noise generator: chunks of the raw stream -> the normal variates the reference's normal_distribution would
+// return (libstdc++ polar method).  Two launches: mt_generate writes the chunks' raw words, polar_slab_kernel
+// reads them ONCE — acceptance test of every trial (raw words 2t, 2t+1), and for each accepted trial its two normals
+// y*mult, x*mult, compacted in stream order into the chunk's SLAB (the workgroups of a chunk, 2048 trials each, chain
+// their counts by decoupled look-back: no separate counting pass, no global prefix sum between the test and the
+// compaction).  counts[i] = accepted trials of chunk i.
+struct NormalsArgs
 {
-    uint64_t accepted;      // accepted trials among those scanned
-    uint64_t trials_used;   // trials consumed up to and including the one that supplied pair `want-1`
-    uint32_t enough;        // 1 if accepted >= want
-    uint32_t pad;
+    const uint64_t *ring;
+    uint32_t ring_rows, first_row;
+    uint32_t n_chunks;
+    uint32_t blocks;      // twist blocks (312 words = 156 trials each) every chunk of this launch generates
+    int pack;             // generator: chunks per workgroup (launch_mt_generate)
+    uint64_t *raw;        // scratch: n_chunks * 312 * blocks words
+    uint64_t *lookback;   // scratch: n_chunks * (ceil(156 * blocks / kSlabBlock) + 1) words (zeroed by the launcher)
+    uint64_t *slabs;      // chunk i writes slabs[i * slab_words ..): 2 words per accepted pair
+    uint64_t slab_words;
+    uint32_t *counts;     // [n_chunks]
+    int write_normals;    // 0: count only (stream_skip, locate)
+    // locate: in chunk locate_chunk (index in this launch; 0xFFFFFFFF = none) the chunk-local trial index of the accepted
+    // pair with chunk-local rank locate_rank (0xFFFFFFFF = the chunk's last accepted pair) is written to *locate_out
+    uint32_t locate_chunk, locate_rank;
+    uint64_t *locate_out;
 };
-constexpr uint32_t kScanBlock = 2048;
-int launch_polar_scan(const uint64_t *raw, uint64_t n_trials, uint64_t want_pairs, uint32_t *block_counts,
-                      uint64_t *block_offsets, uint64_t *pairs_out, ScanResult *result, void *stream);
-// the same in two halves, for a rank that owns a PIECE of the raw stream (sharded simulation): count the accepted
-// trials of n_trials = piece + margin trials per block and report how many lie in the first piece_trials
-// (result->accepted; a multiple of kScanBlock) and in all of them (result_all->accepted); then, once the ranks have
-// exchanged their counts, compact the first want_pairs accepted pairs
-int launch_polar_count(const uint64_t *raw, uint64_t n_trials, uint64_t piece_trials, uint32_t *block_counts,
-                       uint64_t *block_offsets, ScanResult *result, ScanResult *result_all, void *stream);
-int launch_polar_compact(const uint64_t *raw, uint64_t n_trials, const uint64_t *block_offsets, uint64_t want_pairs,
-                         uint64_t *pairs_out, ScanResult *result, void *stream);
+constexpr uint32_t kSlabBlock = 2048; // trials per workgroup of the slab kernel
+inline uint64_t normals_lookback_words(uint32_t n_chunks, uint32_t blocks)
+{
+    return static_cast<uint64_t>(n_chunks) * ((static_cast<uint64_t>(kBlockTrials) * blocks + kSlabBlock - 1) / kSlabBlock + 1);
+}
+int launch_mt_normals(const NormalsArgs &a, void *stream);
+
+// One small launch after the generator: cum[0..n] = exclusive prefix sums of counts[0..n) (the decode kernels' slab
+// table), and where the consumer stands afterwards.
+struct NormalsResult
+{
+    uint64_t total;      // cum[n]
+    uint64_t piece;      // cum[n_piece] (sharded stream: accepted pairs of the rank's piece, without the margin chunk)
+    uint64_t next_k;     // ... at this chunk-local pair index
+    uint32_t next_slab;  // the pair with list index `target` sits in this slab ...
+    uint32_t enough;     // total >= need
+};
+// target: list index (over the concatenated slabs) of the first pair the consumer has NOT used; n_full: leading chunks that
+// were generated to full length (n or n - 1).  When target lies beyond everything generated, the position is
+// (n, target - total) if the last chunk is complete and (n - 1, target - cum[n-1]) if it is a prefix that can be extended.
+int launch_normals_finish(const uint32_t *counts, uint32_t n, uint32_t n_piece, uint32_t n_full, uint64_t need, uint64_t target,
+                          uint64_t *cum, NormalsResult *result, void *stream);
 
 // GF(2) encoding on the reference's info-word stream (channel.cpp:44-60, sparse.h:163-172).
 // The reference draws kc bernoulli(0.5) bits per frame from mt19937_64(seed << 1) and ACCUMULATES u*G
@@ -237,6 +271,8 @@ enum MathFn : int
     kMathCnRatio8,
     kMathCnLlr4,        // cn_core<4, sum-product> (LLR domain, E-form recursion)
     kMathCnLlr6,
+    kMathCnRatio3s,     // dm_cn3_shared / dm_cn4_shared: the shared-reciprocal forms
+    kMathCnRatio4s,
     kMathCount
 };
 int math_selftest_width(int fn); // values per element in a / out (0 = unknown function)

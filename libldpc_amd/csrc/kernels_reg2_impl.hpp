@@ -41,8 +41,10 @@ namespace ldpc_amd
 namespace
 {
 
+// RATIO (always with early termination here): nodes of degree 3 and 4 in the shared-reciprocal form (detmath.h); a
+// denominator product beyond its range marks the frame as escaped
 template <bool MINSUM, bool RATIO, int MAXD>
-__device__ __forceinline__ void cn_regs2(double (&m)[MAXD], int degree)
+__device__ __forceinline__ void cn_regs2(double (&m)[MAXD], int degree, uint32_t &escaped)
 {
     // wave-uniform degree: one fully unrolled recursion per width
 #define LDPC_CASE(D)                                                \
@@ -51,7 +53,7 @@ __device__ __forceinline__ void cn_regs2(double (&m)[MAXD], int degree)
         double v[D];                                                \
         _Pragma("unroll") for (int j = 0; j < D; ++j) v[j] = m[j];  \
         if constexpr (RATIO)                                        \
-            cn_ratio<D>(v);                                         \
+            cn_ratio<D, true>(v, &escaped);                         \
         else                                                        \
             cn_core<D, MINSUM>(v);                                  \
         _Pragma("unroll") for (int j = 0; j < D; ++j) m[j] = v[j];  \
@@ -316,10 +318,10 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
                  if constexpr (!UCN)
                  {
                      if (deg[Ks] >= 2)
-                         cn_regs2<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks]);
+                         cn_regs2<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks], escaped);
                  }
                  else if constexpr (RATIO)
-                     cn_ratio<MAXD>(m[Ks]);
+                     cn_ratio<MAXD, true>(m[Ks], &escaped);
                  else
                      cn_core<MAXD, MINSUM>(m[Ks]);
              }()),

@@ -11,16 +11,22 @@
 // shared memory instead, for rehearsals with a repeated device such as --devices 0,0); --bec-compat (reproduce the
 // reference's out-of-bounds read for erased degree-1 variable nodes).
 #include <fcntl.h>
+#include <signal.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cctype>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ldpc_amd.h"
@@ -195,9 +201,68 @@ int main(int argc, char *argv[])
         }
         device = devices[rank];
     }
+    // Rank 0 watches its rank processes while it works: a rank that dies (no usable device, a HIP error, a signal) would
+    // otherwise leave the others — and this process — waiting in the next collective for ever.  The watcher ends the
+    // remaining ranks and the whole run with a non-zero status; the ranks themselves die with their parent.
+    static std::atomic<bool> watch_on{false};
+    static std::vector<pid_t> watched;
+    static std::mutex watch_mu;
+    std::thread watcher;
+    if (world > 1 && rank == 0)
+    {
+        watched = children;
+        watch_on = true;
+        watcher = std::thread([] {
+            while (watch_on.load())
+            {
+                {
+                    std::lock_guard<std::mutex> lk(watch_mu);
+                    for (pid_t &c : watched)
+                    {
+                        if (c <= 0)
+                            continue;
+                        int st = 0;
+                        const pid_t r = waitpid(c, &st, WNOHANG);
+                        if (r == c)
+                        {
+                            const bool ok = WIFEXITED(st) && WEXITSTATUS(st) == 0;
+                            c = ok ? 0 : -1;
+                            if (!ok && watch_on.load())
+                            {
+                                std::fprintf(stderr, "Error: a rank process ended abnormally (status 0x%x): stopping the run\n", st);
+                                for (pid_t o : watched)
+                                    if (o > 0)
+                                        kill(o, SIGTERM);
+                                std::fflush(nullptr);
+                                _exit(EXIT_FAILURE);
+                            }
+                        }
+                    }
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            }
+        });
+    }
+    else if (world > 1)
+        prctl(PR_SET_PDEATHSIG, SIGTERM);
     auto reap = [&](int rc) {
-        for (pid_t c : children)
+        if (watcher.joinable())
         {
+            watch_on = false;
+            watcher.join();
+        }
+        std::lock_guard<std::mutex> lk(watch_mu);
+        for (size_t i = 0; i < children.size(); ++i)
+        {
+            const pid_t c = children[i];
+            if (i < watched.size() && watched[i] <= 0) // already collected by the watcher
+            {
+                if (watched[i] < 0)
+                    rc = rc ? rc : EXIT_FAILURE;
+                continue;
+            }
+            if (rc != 0)
+                kill(c, SIGTERM); // this rank failed: the others would wait for it
             int st = 0;
             if (waitpid(c, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
                 rc = rc ? rc : EXIT_FAILURE;
@@ -209,7 +274,7 @@ int main(int argc, char *argv[])
     if (!ctx)
     {
         std::cout << "Error: ldpc_code(): " << ldpc_hip_last_error() << std::endl; // ldpc.cpp:16-20
-        return EXIT_FAILURE;
+        return reap(EXIT_FAILURE);
     }
     ldpc_hip_set_bec_compat(ctx, bec_compat);
     int64_t info[10];

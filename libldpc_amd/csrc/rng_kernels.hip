@@ -4,19 +4,21 @@
 // (src/sim/channel.cpp:5-15,37-42), through libstdc++'s normal_distribution (Marsaglia polar
 // method with rejection: a data-dependent number of draws per sample).  To keep frame f the f-th
 // frame of that very stream while decoding tens of thousands of frames per launch, the stream is
-// produced in three data-parallel steps:
+// cut into chunks of a fixed number of 312-word twist blocks and produced in data-parallel steps:
 //
-//   mt_jump_kernel      start state of every chunk of the stream, by GF(2) jump-ahead
+//   mt_jump_kernel      start state of a chunk from the start state of an earlier one, by GF(2) jump-ahead
 //                       (state_{n+J} = g_J(T) state_n; evaluated as a sliding XOR of sequence
 //                       words selected by the coefficients of g_J = t^J mod charpoly),
-//   mt_generate_kernel  one wave per chunk regenerates its 312-word state in LDS and writes the
-//                       tempered 64-bit outputs, 512 B per store instruction,
-//   polar_*_kernel      evaluates the polar acceptance test of every trial in parallel,
-//                       prefix-sums the accept flags and compacts the accepted (u1,u2) pairs in
-//                       stream order, so that normal number g is element g&1 of pair g>>1.
+//   mt_generate_kernel  three waves per chunk regenerate its 312-word state in LDS block by block and write the tempered
+//                       64-bit outputs,
+//   polar_slab_kernel   AWGN: reads the raw words once: polar acceptance test of every trial (raw words 2t, 2t+1), and
+//                       the two normals of each accepted trial, compacted in stream order into the chunk's slab (the
+//                       workgroups of a chunk chain their counts by decoupled look-back: one pass, no counting launch),
+//   normals_finish      prefix sums of the chunks' accepted-pair counts: the table by which the decode kernels find
+//                       normal g as element g&1 of pair g>>1 (device_channel.hpp),
+//                       BSC / BEC / info words use the raw words themselves: one draw per bit.
 //
-// The arithmetic of the acceptance test is device_math.hpp::polar_trial — the same code the
-// decoder prologue uses to turn a pair into two normals.
+// The arithmetic of the acceptance test is device_math.hpp::polar_trial.
 #include <hip/hip_runtime.h>
 
 #include "device_math.hpp"
@@ -60,8 +62,15 @@ __device__ __forceinline__ void mt_regenerate(uint64_t *x, int lane)
 // (kGenChunks = 1 when the decode kernel shares its CUs anyway: packed chunks lengthen the serial chain, which then
 // outlasts the headline decode kernel it runs under)
 constexpr int kGenThreads = 192;
+
+__device__ __forceinline__ uint32_t ring_index(uint32_t rows, uint32_t first, uint32_t i)
+{
+    const uint32_t r = first + i; // first < rows, i < rows
+    return r >= rows ? r - rows : r;
+}
+
 template <int kGenChunks>
-__global__ __launch_bounds__(kGenThreads *kGenChunks) void mt_generate_kernel(const uint64_t *states, uint64_t *next_last,
+__global__ __launch_bounds__(kGenThreads *kGenChunks) void mt_generate_kernel(const uint64_t *ring, uint32_t ring_rows, uint32_t first_row,
                                                                               uint64_t *out, uint32_t chunk_words, uint32_t n_chunks)
 {
     __shared__ uint64_t xs[kGenChunks][kMtN];
@@ -70,10 +79,12 @@ __global__ __launch_bounds__(kGenThreads *kGenChunks) void mt_generate_kernel(co
     const bool live = c < n_chunks; // (the last workgroup may hold fewer chunks; its idle waves still meet the barriers)
     const bool act = live && t < 156;
     uint64_t *x = xs[sub];
-    const uint64_t *s = states + c * kMtN;
     if (live)
+    {
+        const uint64_t *s = ring + static_cast<size_t>(ring_index(ring_rows, first_row, static_cast<uint32_t>(c))) * kMtN;
         for (int k = t; k < kMtN; k += kGenThreads)
             x[k] = s[k];
+    }
     __syncthreads();
     uint64_t *o = out + c * chunk_words;
     const uint32_t blocks = chunk_words / kMtN;
@@ -104,9 +115,6 @@ __global__ __launch_bounds__(kGenThreads *kGenChunks) void mt_generate_kernel(co
         }
         __syncthreads();
     }
-    if (next_last && c + 1 == n_chunks) // the window after the last chunk = start state of the next chunk
-        for (int k = t; k < kMtN; k += kGenThreads)
-            next_last[k] = x[k];
 }
 
 // dst = window at position n+J given the window at n: word i of the new window is the XOR of the
@@ -122,19 +130,20 @@ constexpr int kJumpThreads = 320;
 constexpr int kJumpStages = 64;      // 64 * 312 = 19968 >= 19937 taps
 constexpr int kPolyWords = 320;      // 312 coefficient words + zero padding read by the last stage
 
-__global__ __launch_bounds__(kJumpThreads) void mt_jump_kernel(const uint64_t *src, uint64_t *dst,
-                                                               const uint64_t *poly)
+__global__ __launch_bounds__(kJumpThreads) void mt_jump_kernel(uint64_t *table, uint32_t ring_rows, uint32_t src_first,
+                                                               uint32_t dst_first, const uint64_t *poly)
 {
+    const uint64_t *src = table + static_cast<size_t>(ring_index(ring_rows, src_first, blockIdx.x)) * kMtN;
+    uint64_t *dst = table + static_cast<size_t>(ring_index(ring_rows, dst_first, blockIdx.x)) * kMtN;
     __shared__ uint64_t x[kMtN];        // generator state = newest block
     __shared__ uint64_t ring[2 * kMtN];
     __shared__ uint64_t g[kPolyWords];
     const int tid = threadIdx.x;
-    const uint64_t t = blockIdx.x;
     for (int k = tid; k < kPolyWords; k += kJumpThreads)
         g[k] = poly[k];
     if (tid < kMtN)
     {
-        uint64_t v = src[t * kMtN + tid];
+        uint64_t v = src[tid];
         x[tid] = v;
         ring[tid] = v;
     }
@@ -186,212 +195,255 @@ __global__ __launch_bounds__(kJumpThreads) void mt_jump_kernel(const uint64_t *s
         __syncthreads();
     }
     if (tid < kMtN)
-        dst[t * kMtN + tid] = acc;
+        dst[tid] = acc; // (the task's own source row was read into LDS at the start: in place is fine)
 }
 
-// ---- polar acceptance scan -------------------------------------------------------------------
-constexpr int kScanThreads = 256;
-constexpr int kScanIters = kScanBlock / kScanThreads; // trials per thread
+// ---- AWGN: raw chunk -> slab of normals -------------------------------------------------------------------------
+constexpr int kSlabThreads = 256;
+constexpr int kSlabIters = kSlabBlock / kSlabThreads; // trials per thread
+constexpr unsigned long long kLbPrefix = 1ull << 63, kLbAggregate = 1ull << 62, kLbValue = (1ull << 62) - 1;
 
-__device__ __forceinline__ bool trial_accepted(const uint64_t *raw, uint64_t t, uint64_t n_trials)
+// One workgroup = 2048 consecutive trials of one chunk.  Phase 1: the acceptance test of the thread's eight trials (kept
+// in registers), ballots to LDS, the workgroup's count.  Between the phases the workgroups of a chunk chain their counts
+// by decoupled look-back (each publishes its aggregate, adds up its predecessors' until it meets a published prefix,
+// publishes its own prefix): a single pass over the raw words, no counting launch before the compaction.  Workgroups take
+// their place in their chunk's line from a ticket counter, so a workgroup only ever waits for workgroups that started before it.
+// Phase 2: every accepted trial is written to the chunk's slab at its rank in stream order, as its two normals.
+__global__ __launch_bounds__(kSlabThreads) void polar_slab_kernel(NormalsArgs a, uint32_t trials, uint32_t blocks_per_chunk)
 {
-    if (t >= n_trials)
-        return false;
-    const ulonglong2 u = *reinterpret_cast<const ulonglong2 *>(raw + 2 * t);
-    return polar_trial(u.x, u.y).accepted();
-}
-
-__global__ __launch_bounds__(kScanThreads) void polar_count_kernel(const uint64_t *raw, uint64_t n_trials,
-                                                                   uint32_t *block_counts)
-{
-    __shared__ int total;
-    if (threadIdx.x == 0)
-        total = 0;
-    __syncthreads();
-    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanBlock;
-    int cnt = 0;
-#pragma unroll
-    for (int it = 0; it < kScanIters; ++it)
-        cnt += trial_accepted(raw, base + it * kScanThreads + threadIdx.x, n_trials);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        cnt += __shfl_xor(cnt, o, 64);
-    if ((threadIdx.x & 63) == 0)
-        atomicAdd(&total, cnt);
-    __syncthreads();
-    if (threadIdx.x == 0)
-        block_counts[blockIdx.x] = static_cast<uint32_t>(total);
-}
-
-// single-workgroup exclusive scan of the block counts
-__global__ __launch_bounds__(1024) void polar_offsets_kernel(const uint32_t *block_counts, uint32_t n_blocks,
-                                                             uint64_t *block_offsets, uint64_t want,
-                                                             ScanResult *result)
-{
-    __shared__ uint64_t part[1024];
-    const int tid = threadIdx.x;
-    const uint32_t per = (n_blocks + 1023) / 1024;
-    const uint32_t lo = tid * per, hi = min(lo + per, n_blocks);
-    uint64_t s = 0;
-    for (uint32_t b = lo; b < hi; ++b)
-        s += block_counts[b];
-    part[tid] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) // Hillis-Steele inclusive scan
-    {
-        uint64_t v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint64_t run = tid ? part[tid - 1] : 0;
-    for (uint32_t b = lo; b < hi; ++b)
-    {
-        block_offsets[b] = run;
-        run += block_counts[b];
-    }
-    if (tid == 1023)
-    {
-        result->accepted = part[1023];
-        result->enough = part[1023] >= want;
-        if (want == 0)
-            result->trials_used = 0;
-    }
-}
-
-// Registers: the kernel runs under the decode kernel of the previous batch, whose five waves per SIMD leave 32 VGPRs
-// of each SIMD lane free (512 - 5 x 96).  A wave that fits there starts in a slot the decoder cannot use; one that
-// does not waits for a decode workgroup to retire and keeps the next one out.  Hence the ballots live in LDS and the
-// second phase is a rolled loop with one instance of the polar arithmetic.
-__global__ __launch_bounds__(kScanThreads) void polar_compact_kernel(const uint64_t *raw, uint64_t n_trials,
-                                                                     const uint64_t *block_offsets, uint64_t want,
-                                                                     uint64_t *pairs_out, ScanResult *result)
-{
-    constexpr int kWaves = kScanThreads / 64;
-    __shared__ unsigned long long ballot[kScanIters * kWaves]; // accepted lanes of (it, wave): trials in ascending order
-    __shared__ int first[kScanIters * kWaves];                 // accepted trials of the block before (it, wave)
+    constexpr int kWaves = kSlabThreads / 64;
+    __shared__ unsigned long long ballot[kSlabIters * kWaves]; // accepted lanes of (it, wave): trials in ascending order
+    __shared__ uint32_t first[kSlabIters * kWaves];            // accepted trials of the workgroup before (it, wave)
+    __shared__ uint32_t s_ticket, s_base, s_count;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t off = block_offsets[blockIdx.x];
-    if (off >= want) // nothing this block holds is needed
-        return;
-    const uint64_t base = static_cast<uint64_t>(blockIdx.x) * kScanBlock;
-#pragma unroll 2
-    for (int it = 0; it < kScanIters; ++it)
+    unsigned long long *lb = reinterpret_cast<unsigned long long *>(a.lookback);
+    // the workgroup's chunk is fixed by its index; its place in the chunk's line is a ticket of that chunk's counter (one
+    // counter per chunk: a single counter for all 21 000 workgroups of a batch serialises them on one address)
+    const uint32_t chunk = blockIdx.x / blocks_per_chunk;
+    if (tid == 0)
+        s_ticket = atomicAdd(reinterpret_cast<unsigned int *>(lb + static_cast<uint64_t>(a.n_chunks) * blocks_per_chunk + chunk), 1u);
+    __syncthreads();
+    const uint32_t blk = s_ticket;
+    const uint64_t *raw = a.raw + static_cast<uint64_t>(chunk) * (2ull * kBlockTrials * a.blocks);
+    const uint32_t base = blk * kSlabBlock;
+    PolarTrial tr[kSlabIters];
+    bool acc[kSlabIters];
+#pragma unroll
+    for (int it = 0; it < kSlabIters; ++it)
     {
-        const unsigned long long m = __ballot(trial_accepted(raw, base + it * kScanThreads + tid, n_trials));
+        const uint32_t t = base + it * kSlabThreads + tid;
+        ulonglong2 u = {0, 0};
+        if (t < trials)
+            u = *reinterpret_cast<const ulonglong2 *>(raw + 2 * static_cast<uint64_t>(t));
+        tr[it] = polar_trial(u.x, u.y);
+        acc[it] = t < trials && tr[it].accepted();
+        const unsigned long long m = __ballot(acc[it]);
         if (lane == 0)
             ballot[it * kWaves + wave] = m;
     }
     __syncthreads();
-    if (tid == 0)
+    if (wave == 0)
     {
-        int run = 0;
-        for (int i = 0; i < kScanIters * kWaves; ++i)
+        // the workgroup's 32 ballots -> exclusive counts (one lane each, a shuffle scan) and the workgroup's total
+        static_assert(kSlabIters * kWaves <= 64, "one lane per ballot");
+        const uint32_t own = lane < kSlabIters * kWaves ? __popcll(ballot[lane]) : 0u;
+        uint32_t incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
         {
-            first[i] = run;
-            run += __popcll(ballot[i]);
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (lane >= o)
+                incl += up;
+        }
+        if (lane < kSlabIters * kWaves)
+            first[lane] = incl - own;
+        const uint32_t run = __shfl(incl, 63, 64);
+        // decoupled look-back, a wave at a time: lane l inspects the predecessor l places back; the nearest published
+        // prefix ends the walk, aggregates on the way are added.  The count travels in the same word as the flag: relaxed
+        // atomics at device scope are all the ordering this needs.
+        unsigned long long excl = 0;
+        unsigned long long *mine = lb + static_cast<uint64_t>(chunk) * blocks_per_chunk;
+        if (blk > 0)
+        {
+            if (lane == 0)
+                __hip_atomic_store(mine + blk, kLbAggregate | run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t j = static_cast<int64_t>(blk) - 1;
+            for (;;)
+            {
+                const int64_t idx = j - lane;
+                // (before block 0 of the chunk: a prefix of zero)
+                const unsigned long long v = idx >= 0 ? __hip_atomic_load(mine + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kLbPrefix;
+                const unsigned long long pm = __ballot((v & kLbPrefix) != 0), nr = __ballot(v == 0);
+                const int cut = pm ? __builtin_ctzll(pm) : 63; // lanes 0..cut are needed
+                const unsigned long long need = cut == 63 ? ~0ull : (2ull << cut) - 1;
+                if (nr & need)
+                {
+                    __builtin_amdgcn_s_sleep(2); // a predecessor with an earlier ticket has not published yet: it is running
+                    continue;
+                }
+                unsigned long long c = lane <= cut ? (v & kLbValue) : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+                    c += __shfl_xor(c, o, 64);
+                excl += c;
+                if (pm)
+                    break;
+                j -= 64;
+            }
+        }
+        if (lane == 0)
+        {
+            __hip_atomic_store(mine + blk, kLbPrefix | (excl + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base = static_cast<uint32_t>(excl);
+            s_count = run;
+            if (blk + 1 == blocks_per_chunk)
+                a.counts[chunk] = static_cast<uint32_t>(excl + run);
         }
     }
     __syncthreads();
-#pragma clang loop unroll(disable)
-    for (int it = 0; it < kScanIters; ++it)
+    const uint32_t wg_base = s_base, wg_last = s_base + s_count - 1;
+    uint64_t *slab = a.slabs + static_cast<uint64_t>(chunk) * a.slab_words;
+    const bool locating = chunk == a.locate_chunk;
+    const unsigned long long below = (1ull << lane) - 1;
+#pragma unroll
+    for (int it = 0; it < kSlabIters; ++it)
     {
-        const unsigned long long m = ballot[it * kWaves + wave];
-        if (!(m >> lane & 1))
+        if (!acc[it])
             continue;
-        const uint64_t rank = off + first[it * kWaves + wave] + __popcll(m & ((1ull << lane) - 1));
-        if (rank >= want)
-            continue;
-        const uint64_t t = base + it * kScanThreads + tid;
-        if (pairs_out)
+        const uint32_t rank = wg_base + first[it * kWaves + wave] + __popcll(ballot[it * kWaves + wave] & below);
+        if (a.write_normals)
         {
             // the accepted trial leaves here as its two normals (libstdc++ normal_distribution, polar method: y*mult is
             // returned first, x*mult saved for the next call), so the decode launch finds finished variates instead of
             // a log/divide/sqrt chain at the head of every frame
-            const ulonglong2 u = *reinterpret_cast<const ulonglong2 *>(raw + 2 * t);
-            const PolarTrial tr = polar_trial(u.x, u.y);
-            __builtin_amdgcn_sched_barrier(0); // (stage by stage: the scheduler's interleaving costs 20 registers)
-            const double lg = dm_log(tr.r2);
-            __builtin_amdgcn_sched_barrier(0);
-            const double q = -2 * lg / tr.r2;
-            __builtin_amdgcn_sched_barrier(0);
+            const double lg = dm_log(tr[it].r2);
+            const double q = -2 * lg / tr[it].r2;
             const double mult = __builtin_sqrt(q);
-            __builtin_amdgcn_sched_barrier(0);
             ulonglong2 o;
-            o.x = dm_bits(tr.y * mult), o.y = dm_bits(tr.x * mult);
-            *reinterpret_cast<ulonglong2 *>(pairs_out + 2 * rank) = o;
+            o.x = dm_bits(tr[it].y * mult), o.y = dm_bits(tr[it].x * mult);
+            *reinterpret_cast<ulonglong2 *>(slab + 2 * static_cast<uint64_t>(rank)) = o;
         }
-        if (rank == want - 1)
-            result->trials_used = t + 1;
+        // (the chunk's last accepted pair: the last one of the chunk's last workgroup that holds any — later workgroups
+        // of the chunk overwrite the answer of earlier ones only if they hold an accepted pair themselves; stream order
+        // of the writes does not matter because only the chunk's final count decides, see the host side)
+        if (locating && (a.locate_rank == 0xFFFFFFFFu ? rank == wg_last : rank == a.locate_rank))
+        {
+            const uint64_t t = base + it * kSlabThreads + tid;
+            if (a.locate_rank == 0xFFFFFFFFu)
+                atomicMax(reinterpret_cast<unsigned long long *>(a.locate_out), static_cast<unsigned long long>(t));
+            else
+                *a.locate_out = t;
+        }
+    }
+}
+
+// exclusive prefix sums of the chunk counts + where the consumer stands afterwards (kernels.hpp, NormalsResult)
+__global__ __launch_bounds__(256) void normals_finish_kernel(const uint32_t *counts, uint32_t n, uint32_t n_piece, uint32_t n_full,
+                                                             uint64_t need, uint64_t target, uint64_t *cum, NormalsResult *result)
+{
+    __shared__ uint64_t part[256];
+    const int tid = threadIdx.x;
+    const uint32_t per = (n + 255) / 256;
+    const uint32_t lo = min(tid * per, n), hi = min(lo + per, n);
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i)
+        s += counts[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) // Hillis-Steele inclusive scan
+    {
+        const uint64_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint64_t runsum = tid ? part[tid - 1] : 0;
+    const uint64_t total = part[255];
+    if (tid == 0)
+    {
+        cum[n] = total;
+        result->total = total;
+        result->enough = total >= need;
+        if (target >= total) // beyond everything generated
+        {
+            const uint32_t j = n_full >= n ? n : n - 1;
+            result->next_slab = j;
+            result->next_k = target - (j == n ? total : total - counts[n - 1]);
+        }
+        if (n_piece >= n)
+            result->piece = total;
+    }
+    for (uint32_t i = lo; i < hi; ++i)
+    {
+        cum[i] = runsum;
+        if (i == n_piece)
+            result->piece = runsum;
+        const uint64_t next = runsum + counts[i];
+        if (runsum <= target && target < next)
+        {
+            result->next_slab = i;
+            result->next_k = target - runsum;
+        }
+        runsum = next;
     }
 }
 
 } // namespace
 
-int launch_mt_generate(const uint64_t *states, uint64_t *next_last, uint64_t *out, uint32_t n_chunks,
-                       uint32_t chunk_words, int chunks_per_workgroup, void *stream)
+int launch_mt_generate(const uint64_t *ring, uint32_t ring_rows, uint32_t first_row, uint64_t *out, uint32_t n_chunks,
+                       uint32_t chunk_words, int pack, void *stream)
 {
     if (n_chunks == 0)
         return hipSuccess;
-    if (chunk_words % kMtN != 0)
+    if (chunk_words % kMtN != 0 || first_row >= ring_rows || n_chunks > ring_rows)
         return hipErrorInvalidValue;
-    if (chunks_per_workgroup >= 4)
+    if (pack >= 4)
         hipLaunchKernelGGL(mt_generate_kernel<4>, dim3((n_chunks + 3) / 4), dim3(kGenThreads * 4), 0, static_cast<hipStream_t>(stream),
-                           states, next_last, out, chunk_words, n_chunks);
+                           ring, ring_rows, first_row, out, chunk_words, n_chunks);
     else
-        hipLaunchKernelGGL(mt_generate_kernel<1>, dim3(n_chunks), dim3(kGenThreads), 0, static_cast<hipStream_t>(stream), states,
-                           next_last, out, chunk_words, n_chunks);
+        hipLaunchKernelGGL(mt_generate_kernel<1>, dim3(n_chunks), dim3(kGenThreads), 0, static_cast<hipStream_t>(stream), ring,
+                           ring_rows, first_row, out, chunk_words, n_chunks);
     return hipGetLastError();
 }
 
-int launch_mt_jump(const uint64_t *src_states, uint64_t *dst_states, const uint64_t *poly, uint32_t n_tasks,
-                   void *stream)
+int launch_mt_jump(uint64_t *ring, uint32_t ring_rows, uint32_t src_first, uint32_t dst_first, const uint64_t *poly,
+                   uint32_t n_tasks, void *stream)
 {
     if (n_tasks == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(mt_jump_kernel, dim3(n_tasks), dim3(kJumpThreads), 0, static_cast<hipStream_t>(stream),
-                       src_states, dst_states, poly);
+    if (src_first >= ring_rows || dst_first >= ring_rows || n_tasks > ring_rows)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mt_jump_kernel, dim3(n_tasks), dim3(kJumpThreads), 0, static_cast<hipStream_t>(stream), ring, ring_rows,
+                       src_first, dst_first, poly);
     return hipGetLastError();
 }
 
-int launch_polar_scan(const uint64_t *raw, uint64_t n_trials, uint64_t want_pairs, uint32_t *block_counts,
-                      uint64_t *block_offsets, uint64_t *pairs_out, ScanResult *result, void *stream)
+int launch_mt_normals(const NormalsArgs &a, void *stream)
 {
+    if (a.n_chunks == 0 || a.blocks == 0)
+        return hipSuccess;
+    const uint32_t trials = kBlockTrials * a.blocks;
+    if (a.first_row >= a.ring_rows || a.n_chunks > a.ring_rows || a.slab_words < 2ull * trials || !a.raw || !a.lookback)
+        return hipErrorInvalidValue;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint32_t n_blocks = static_cast<uint32_t>((n_trials + kScanBlock - 1) / kScanBlock);
-    if (n_blocks == 0)
-        return hipErrorInvalidValue;
-    hipLaunchKernelGGL(polar_count_kernel, dim3(n_blocks), dim3(kScanThreads), 0, s, raw, n_trials, block_counts);
-    hipLaunchKernelGGL(polar_offsets_kernel, dim3(1), dim3(1024), 0, s, block_counts, n_blocks, block_offsets,
-                       want_pairs, result);
-    hipLaunchKernelGGL(polar_compact_kernel, dim3(n_blocks), dim3(kScanThreads), 0, s, raw, n_trials, block_offsets,
-                       want_pairs, pairs_out, result);
+    int rc = launch_mt_generate(a.ring, a.ring_rows, a.first_row, a.raw, a.n_chunks, kMtN * a.blocks, a.pack, stream);
+    if (rc != hipSuccess)
+        return rc;
+    const uint32_t bpc = (trials + kSlabBlock - 1) / kSlabBlock;
+    rc = hipMemsetAsync(a.lookback, 0, 8 * normals_lookback_words(a.n_chunks, a.blocks), s);
+    if (rc != hipSuccess)
+        return rc;
+    hipLaunchKernelGGL(polar_slab_kernel, dim3(a.n_chunks * bpc), dim3(kSlabThreads), 0, s, a, trials, bpc);
     return hipGetLastError();
 }
 
-int launch_polar_count(const uint64_t *raw, uint64_t n_trials, uint64_t piece_trials, uint32_t *block_counts,
-                       uint64_t *block_offsets, ScanResult *result, ScanResult *result_all, void *stream)
+int launch_normals_finish(const uint32_t *counts, uint32_t n, uint32_t n_piece, uint32_t n_full, uint64_t need, uint64_t target,
+                          uint64_t *cum, NormalsResult *result, void *stream)
 {
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint32_t n_blocks = static_cast<uint32_t>((n_trials + kScanBlock - 1) / kScanBlock);
-    if (n_blocks == 0 || piece_trials % kScanBlock != 0 || piece_trials > n_trials)
+    if (n == 0)
         return hipErrorInvalidValue;
-    const uint32_t piece_blocks = static_cast<uint32_t>(piece_trials / kScanBlock);
-    hipLaunchKernelGGL(polar_count_kernel, dim3(n_blocks), dim3(kScanThreads), 0, s, raw, n_trials, block_counts);
-    // offsets of the piece's blocks (gives the piece's total), then of all blocks (the ones the compaction uses)
-    hipLaunchKernelGGL(polar_offsets_kernel, dim3(1), dim3(1024), 0, s, block_counts, piece_blocks, block_offsets, 0ull, result);
-    hipLaunchKernelGGL(polar_offsets_kernel, dim3(1), dim3(1024), 0, s, block_counts, n_blocks, block_offsets, 0ull, result_all);
-    return hipGetLastError();
-}
-
-int launch_polar_compact(const uint64_t *raw, uint64_t n_trials, const uint64_t *block_offsets, uint64_t want_pairs,
-                         uint64_t *pairs_out, ScanResult *result, void *stream)
-{
-    const uint32_t n_blocks = static_cast<uint32_t>((n_trials + kScanBlock - 1) / kScanBlock);
-    if (n_blocks == 0)
-        return hipErrorInvalidValue;
-    hipLaunchKernelGGL(polar_compact_kernel, dim3(n_blocks), dim3(kScanThreads), 0, static_cast<hipStream_t>(stream), raw, n_trials,
-                       block_offsets, want_pairs, pairs_out, result);
+    hipLaunchKernelGGL(normals_finish_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), counts, n, n_piece, n_full, need,
+                       target, cum, result);
     return hipGetLastError();
 }
 

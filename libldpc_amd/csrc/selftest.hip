@@ -27,6 +27,20 @@ __device__ void cn_ratio_rows(uint64_t i, const double *a, double *out)
 }
 
 template <int D>
+__device__ void cn_shared_rows(uint64_t i, const double *a, double *out)
+{
+    double v[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        v[j] = a[i * D + j];
+    uint32_t escaped = 0;
+    cn_ratio<D, true>(v, &escaped);
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        out[i * D + j] = DM_RATIO_ESCAPED(escaped) ? __builtin_nan("") : v[j];
+}
+
+template <int D>
 __device__ void cn_llr_rows(uint64_t i, const double *a, double *out)
 {
     double v[D];
@@ -63,6 +77,8 @@ __global__ __launch_bounds__(256) void math_selftest_kernel(int fn, uint64_t n, 
     case kMathCnRatio8: cn_ratio_rows<8>(i, a, out); break;
     case kMathCnLlr4: cn_llr_rows<4>(i, a, out); break;
     case kMathCnLlr6: cn_llr_rows<6>(i, a, out); break;
+    case kMathCnRatio3s: cn_shared_rows<3>(i, a, out); break;
+    case kMathCnRatio4s: cn_shared_rows<4>(i, a, out); break;
     default: break;
     }
 }
@@ -73,8 +89,8 @@ int math_selftest_width(int fn)
 {
     switch (fn)
     {
-    case kMathCnRatio3: return 3;
-    case kMathCnRatio4: case kMathCnLlr4: return 4;
+    case kMathCnRatio3: case kMathCnRatio3s: return 3;
+    case kMathCnRatio4: case kMathCnLlr4: case kMathCnRatio4s: return 4;
     case kMathCnRatio5: return 5;
     case kMathCnRatio6: case kMathCnLlr6: return 6;
     case kMathCnRatio8: return 8;

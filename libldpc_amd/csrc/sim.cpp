@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -81,24 +82,41 @@ int run_simulation_sharded(Engine &eng, const SimRequest &rq, sim_results_t *res
         uint64_t bec = 0, fec = 0, frames = 0, iters = 0;
         const auto t_start = clock::now();
         eng.stream_begin(rq.channel, rq.seed, xs[i], /*fresh=*/i == 0);
-        const uint64_t max_step = std::min<uint64_t>(rq.max_batch, eng.max_sub_batch() * 15 / 16 - 64) * R;
+        const uint64_t msb = eng.max_sub_batch() * 3 / 4; // (a piece may hold a few per cent more frames than its share)
+        const uint64_t max_step = std::max<uint64_t>(1, std::min<uint64_t>(rq.max_batch, msb)) * R;
         const uint64_t min_step = std::min<uint64_t>(rq.first_batch, max_step);
         uint64_t step = min_step;
         bool go = true;
         while (go)
         {
-            const uint64_t cap = Engine::shard_capacity(step, R);
+            const uint64_t cap = eng.shard_capacity(step, R);
             it_buf.resize(cap), be_buf.resize(cap);
             BatchOut out;
             out.iters = it_buf.data(), out.bit_errors = be_buf.data();
-            eng.encoder_snapshot(nullptr);
-            const Engine::ShardStep st = eng.stream_decode_sharded(comm, rq.dec, step, out, nullptr);
-            // every rank's range as if all of it counted; the ranks before the one holding the stopping frame do
-            const Fold mine = fold_range(it_buf.data(), be_buf.data(), st.n, 0, 0, kNoLimit, kNoLimit);
+            // A rank whose step fails (a HIP error, a device that went away) still takes part in the exchange below and says
+            // so in the last word: every rank then leaves the loop with an error instead of waiting for the one that is gone.
+            Engine::ShardStep st;
+            std::string step_error;
+            Fold mine;
+            try
+            {
+                eng.encoder_snapshot(nullptr);
+                st = eng.stream_decode_sharded(comm, rq.dec, step, out, nullptr);
+                // every rank's range as if all of it counted; the ranks before the one holding the stopping frame do
+                mine = fold_range(it_buf.data(), be_buf.data(), st.n, 0, 0, kNoLimit, kNoLimit);
+            }
+            catch (const std::exception &e)
+            {
+                step_error = e.what();
+            }
             uint64_t send[8] = {mine.n, mine.fec, mine.bec, mine.iters, mine.n_at_err, mine.iters_at_err,
-                                static_cast<uint64_t>(*stop_flag ? 1 : 0), 0};
+                                static_cast<uint64_t>(*stop_flag ? 1 : 0), step_error.empty() ? 0u : 1u};
             std::vector<uint64_t> all(8 * static_cast<size_t>(R));
             comm.all_gather(send, all.data(), sizeof send);
+            for (int q = 0; q < R; ++q)
+                if (all[8 * static_cast<size_t>(q) + 7])
+                    throw std::runtime_error(q == me ? "sharded simulation: " + step_error
+                                                     : "sharded simulation: the step failed on rank " + std::to_string(q));
             bool any_stop_flag = false, err_seen = false;
             uint64_t err_frames = 0, err_iters = 0, used = 0;
             int q_stop = -1;

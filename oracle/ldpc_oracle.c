@@ -465,12 +465,21 @@ static int is_codeword(const dec_t *d)
  * lambda = e^-L.  Same schedule, same orders of accumulation as decoder.cpp:11-78.  Returns -1 when a value
  * of the frame leaves the representable box; the caller then decodes the frame with the LLR-domain form.
  */
-static void cn_update_ratio(dec_t *d, const int *cn, int cw)
+/* shared: nodes of degree 3 and 4 take one reciprocal of the product of their denominators (detmath.h, "Shared-reciprocal
+   check nodes": what the kernels run WITH early termination); returns nonzero when such a product left its range */
+static int cn_update_ratio(dec_t *d, const int *cn, int cw, int shared)
 {
     enum { MAXD = 64 };
     double v[MAXD] = {0};
     for (int j = 0; j < cw; ++j)
         v[j] = d->v2c[cn[j]];
+    if (shared && (cw == 3 || cw == 4))
+    {
+        const uint32_t p_hi = cw == 3 ? dm_cn3_shared(v) : dm_cn4_shared(v);
+        for (int j = 0; j < cw; ++j)
+            d->c2v[cn[j]] = v[j];
+        return DM_SHARED_OVERFLOW(p_hi);
+    }
     if (cw == 2)
     {
         d->c2v[cn[0]] = 1.0 / v[1];
@@ -517,6 +526,7 @@ static void cn_update_ratio(dec_t *d, const int *cn, int cw)
         for (int j = 2; j <= cw - 3; ++j)
             d->c2v[cn[j]] = dm_frac_lambda2(Ff[j - 1], Bf[j + 1]);
     }
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -567,7 +577,7 @@ static void ref_cn_llr(int cw, const double *v, double *out) /* decoder.cpp:31-4
 
 static int math_width(int fn)
 {
-    static const int w[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 3, 4, 5, 6, 8, 4, 6};
+    static const int w[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 3, 4, 5, 6, 8, 4, 6, 3, 4};
     return fn >= 0 && fn < (int)(sizeof w / sizeof w[0]) ? w[fn] : 0;
 }
 
@@ -606,9 +616,22 @@ static void det_cn_ratio(int cw, const double *v, double *out)
     for (int j = 0; j < cw; ++j)
         v2c[j] = v[j], cn[j] = j;
     d.v2c = v2c, d.c2v = c2v;
-    cn_update_ratio(&d, cn, cw);
+    cn_update_ratio(&d, cn, cw, 0);
     for (int j = 0; j < cw; ++j)
         out[j] = c2v[j];
+}
+
+static void det_cn_shared(int cw, const double *v, double *out) /* rows whose denominator product overflows: NaN */
+{
+    dec_t d;
+    double v2c[16], c2v[16];
+    int cn[16];
+    for (int j = 0; j < cw; ++j)
+        v2c[j] = v[j], cn[j] = j;
+    d.v2c = v2c, d.c2v = c2v;
+    const int over = cn_update_ratio(&d, cn, cw, 1);
+    for (int j = 0; j < cw; ++j)
+        out[j] = over ? NAN : c2v[j];
 }
 
 int orc_math_det(int fn, uint64_t n, const double *a, const double *b, double *out)
@@ -653,6 +676,7 @@ int orc_math_det(int fn, uint64_t n, const double *a, const double *b, double *o
                 out[i * w + j] = c2v[j];
             break;
         }
+        case 17: case 18: det_cn_shared(w, a + i * w, out + i * w); break;
         default: det_cn_ratio(w, a + i * w, out + i * w); break;
         }
     return 0;
@@ -708,7 +732,7 @@ static int dec_decode_ratio(dec_t *d)
                 escaped = 1;
                 break;
             }
-            cn_update_ratio(d, H->redge + H->rptr[i], cw);
+            escaped |= cn_update_ratio(d, H->redge + H->rptr[i], cw, d->early_term);
         }
         if (escaped)
             break;

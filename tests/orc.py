@@ -217,7 +217,7 @@ def ref_dump(h, g, chan, dec, iters, early, seed, x, skip, count, tmp):
 
 
 MATH_FNS = ("exp", "log", "boxplus", "ratio_div", "ratio_rho", "ratio_lambda", "e_combine", "exp_clamped", "boxplus_exp",
-            "boxplus_log", "cn_ratio3", "cn_ratio4", "cn_ratio5", "cn_ratio6", "cn_ratio8", "cn_llr4", "cn_llr6")
+            "boxplus_log", "cn_ratio3", "cn_ratio4", "cn_ratio5", "cn_ratio6", "cn_ratio8", "cn_llr4", "cn_llr6", "cn_ratio3s", "cn_ratio4s")
 
 
 def math_eval(fn, a, b=None, det=False):
@@ -283,6 +283,13 @@ def math_points(fn, n, seed):
         return mix([rng.uniform(0, 710, 2 * k), rng.exponential(5, 2 * k), np.abs(edge)]), None
     if fn == "boxplus_log":
         return mix([rng.uniform(0.5, 2, 3 * k), 1 + rng.normal(0, 1e-6, k), np.array([0.5, 1.0, 2.0])]), None
+    if fn in ("cn_ratio3s", "cn_ratio4s"):
+        # the shared-reciprocal forms: inputs kept where the product of the node's denominators stays below 2^960
+        # (degree 3: |L| <= 100, degree 4: |L| <= 50); beyond that the kernels hand the frame back, covered by whole decodes
+        d, lim = (3, 100.0) if fn == "cn_ratio3s" else (4, 50.0)
+        L = np.concatenate([rng.uniform(-lim, lim, (n // 2, d)), rng.normal(0, 6, (n - n // 2 - 2, d)).clip(-lim, lim),
+                            np.full((1, d), lim), np.full((1, d), -lim)])
+        return np.exp(L), None
     d = int(fn[-1])
     if fn.startswith("cn_ratio"):
         lim = 240 * np.log(2.0) * (1 - 1e-12)

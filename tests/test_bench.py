@@ -57,6 +57,14 @@ def test_roofline_arithmetic_is_a_fraction():
     assert all(v["frac"] <= 1.0 for v in r["ceilings"].values())
     assert abs(r["ceilings"]["valu"]["busy_frac_of_kernel_cycles"] - 0.746) < 0.01
     assert r["traffic"] == (2 * 262144.0 + 512.0) * 1024 and r["algorithmic_equiv_GBs"] > 8000  # reported, not a fraction
+    c.update({"SQ_INSTS_VALU_ADD_F64": 1e8, "SQ_INSTS_VALU_MUL_F64": 3e8, "SQ_INSTS_VALU_FMA_F64": 5e8, "SQ_INSTS_VALU_TRANS_F64": 6e7,
+              "SQ_INSTS_VALU_INT32": 4e8, "SQ_INSTS_VALU_INT64": 0, "SQ_INSTS_VALU_CVT": 1e6, "SQ_INSTS_SALU": 1e9})
+    r = bench.roofline_from({"counters": c, "kernel": "k", "probe": {"edge_updates": 3.15e9, "steps": 1}}, 4.4, 3.15e9, workloads.get("2"))
+    flops = 64 * (1e8 + 3e8 + 2 * 5e8 + 6e7)  # an FMA counts two
+    assert r["bound"] == "valu-fp64" and abs(r["achieved"] - flops / 4.409e-3 / 1e12) < 1e-9 and abs(r["peak"] - 78.6432) < 1e-3
+    assert r["frac"] < r["valu_busy"] and r["ceilings"]["valu"]["frac"] > 0.6  # the busy figure stays, no longer THE fraction
+    r3 = bench.roofline_from({"counters": c, "kernel": "k", "probe": {"edge_updates": 3.15e9, "steps": 1}}, 4.4, 3.15e9, workloads.get("3"))
+    assert r3["bound"] in ("valu", "lds", "hbm")  # min-sum retires hardly any binary64 arithmetic: the on-chip ceilings decide
     r0 = bench.roofline_from(None, 4.4, 3.15e9, workloads.get("2"))
     assert r0["frac"] is None and r0["traffic"] is None
 
@@ -67,7 +75,11 @@ def test_bench_line_headline():
     assert j["n_gpus"] == 1 and j["unit"] == "frames/s" and j["config"]["baseline_config"] == "2"
     assert j["config"]["frames_per_step"] == 65536 and j["dtype"] == "f64" and j["vs_baseline"] is None
     r = j["roofline"]
-    assert r["bound"] in ("valu", "lds", "hbm") and 0 < r["frac"] <= 1.0, r
+    # work-normalised: binary64 operations retired against the 78.6 TFLOP/s vector peak, the busy share beside it
+    assert r["bound"] == "valu-fp64" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < r["valu_busy"] <= 1.0, r
+    mix = r["ceilings"]["fp64"]["lane_instructions_per_edge_update"]
+    assert 0.3 < r["ceilings"]["fp64"]["fp64_share_of_valu_instructions"] < 0.95
+    assert abs(mix["all_valu"] - r["ceilings"]["valu"]["valu_lane_instructions_per_edge_update"]) / mix["all_valu"] < 0.05
     assert r["traffic"] and r["traffic"] > 65536 * 8192  # at least the 8 KB of normals per frame cross HBM
     assert abs(r["profiled_kernel_ms"] - r["kernel_ms_avg"]) / r["kernel_ms_avg"] < 0.25
     assert 1e-4 < j["fer"] < 1e-2 and 12 < j["avg_iter"] < 14
@@ -82,7 +94,7 @@ def test_bench_line_other_configs(cfg):
     if cfg == "1":
         assert j["latency_us"]["median"] < 2000 and j["config"]["frames_per_step"] == 1
     else:
-        assert 0 < j["roofline"]["frac"] <= 1.0, j["roofline"]
+        assert 0 < j["roofline"]["frac"] <= 1.0 and 0 < j["roofline"]["valu_busy"] <= 1.0, j["roofline"]
 
 
 @pytest.mark.gpu
@@ -94,9 +106,10 @@ def test_bench_two_ranks_rehearsal():
     B, K, W = 4096, 2, 1
     j = last_json(run_bench("--gpus", "2", "--steps", str(K), "--warmup", str(W), "--batch", str(B), "--no-cpu-baseline", "--no-pmc",
                             env={"LDPC_BENCH_ONE_GPU": "1", "LDPC_BENCH_BACKEND": "gloo"}))
-    assert j["n_gpus"] == 2 and abs(j["config"]["frames_per_step"] - 2 * B) < 0.02 * B
+    # (a rank's piece is a whole number of 8 MB generator chunks, about 804 frames of this code each: 5 chunks here)
+    assert j["n_gpus"] == 2 and abs(j["config"]["frames_per_step"] - 2 * B) < 0.15 * B
     first, end = j["timed_frame_span"]
-    assert first >= W * 2 * B * 0.98 and end - first == j["counters"]["frames"]
+    assert first >= W * 2 * B * 0.85 and end - first == j["counters"]["frames"]
     dec = libldpc_amd.HipDecoder(os.path.join(ROOT, "tests", "golden", "h.txt"))
     dec.stream_begin("AWGN", 0, -4.0)
     dec.stream_skip(first)
@@ -105,3 +118,11 @@ def test_bench_two_ranks_rehearsal():
     tot = [end - first, int((be > 0).sum()), int(be.sum()), int(it.sum()), int((it < 50).sum())]
     c = j["counters"]
     assert [c["frames"], c["fec"], c["bec"], c["iters"], c["converged"]] == tot
+    # the N-rank line explains itself (round-2 VERDICT): per rank and min / max over ranks
+    rk = j["ranks"]
+    for key in ("kernel_ms_avg", "rng_ms_avg", "host_in_exchange_ms_avg", "host_wait_noise_ms_avg", "comm_init_s", "frames", "frames_per_step"):
+        assert set(rk[key]) == {"min", "max"} and rk[key]["min"] <= rk[key]["max"], key
+    assert len(rk["per_rank"]) == 2 and sorted(r["rank"] for r in rk["per_rank"]) == [0, 1]
+    assert sum(r["frames"] for r in rk["per_rank"]) == c["frames"]
+    assert 0 < j["step_ms"]["min"] <= j["step_ms"]["median_max_over_ranks"] <= j["step_ms"]["max"]
+    assert all(r["kernel_ms_avg"] > 0 and r["step_ms"]["median"] > 0 for r in rk["per_rank"])

@@ -23,11 +23,12 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "math_
 #            rounded three times on BOTH sides (1.1e-16 each, relative to a value in [0.5, 2]), measured 4.4e-16 apart
 #   ratio forms: three roundings (numerator, denominator, quotient) against the exact value -> 3 ulp
 #   check nodes in ratio form: D-2 steps of that, measured 5 ulp at D = 8                -> 8 ulp
+#   shared-reciprocal forms (degree 3, 4): a product of up to four factors and a reciprocal in place of a quotient -> 8 ulp
 #   check nodes in the LLR domain: results up to |L| = 600, 1 ulp(600) = 1.1e-13 per step  -> 4 ulp of the largest input
 TOL = {"exp": (2, 0.0), "log": (2, 1e-300), "boxplus": (2, 6e-16), "ratio_div": (0, 0.0), "ratio_rho": (3, 0.0),
        "ratio_lambda": (3, 0.0), "e_combine": (3, 0.0), "exp_clamped": (2, 0.0), "boxplus_exp": (2, 0.0),
        "boxplus_log": (0, 3.5e-16), "cn_ratio3": (8, 0.0), "cn_ratio4": (8, 0.0), "cn_ratio5": (8, 0.0), "cn_ratio6": (8, 0.0),
-       "cn_ratio8": (8, 0.0), "cn_llr4": (0, 0.0), "cn_llr6": (0, 0.0)}
+       "cn_ratio8": (8, 0.0), "cn_llr4": (0, 0.0), "cn_llr6": (0, 0.0), "cn_ratio3s": (8, 0.0), "cn_ratio4s": (8, 0.0)}
 
 
 def check(fn, a, b, got, ref):

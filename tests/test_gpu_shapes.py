@@ -70,7 +70,7 @@ def test_reference_fixtures_wide_and_irregular(tmp_path):
         if dec == "BP_MS":  # no transcendental in the decoder itself (the channel's normals still carry the polar method's log):
             for k in ("iters", "bit_errors", "hard"):  # every frame, failing ones included
                 assert np.array_equal(got[k], ref[k].astype(got[k].dtype)), (key, k)
-            assert np.abs(got["llr_out"] - ref["llr_out"]).max() < 1e-7, key
+            assert np.abs(got["llr_out"] - ref["llr_out"]).max() < 1e-6, key
     assert n_conv >= 30
 
 

@@ -35,16 +35,39 @@ def test_header_symbols_are_exported(lib):
     assert exported == declared, exported ^ declared  # nothing else leaks out of the library
 
 
-def test_chunk_state_table_never_leaves_its_rows(lib):
-    """Host replay of the noise stream's chunk-state bookkeeping over far more sequential requests than the table has
-    rows (8193: indices 0..8192): a long Monte-Carlo run of one-chunk batches (BSC/BEC batches, the encoder's info
-    stream) must never read or write row 8193, and every requested chunk must have a valid row."""
-    cap = 8192
-    for first, per, n in [(0, 1, 3 * cap + 7), (0, 2, 2 * cap), (0, 3, cap), (5, 64, 2000), (0, cap, 5), (123456, 1, cap + 50),
-                          (0, 7, 4000), (cap - 1, 1, 10), (cap, 1, 10), (0, cap - 1, 3)]:
-        top = lib.ldpc_hip_selftest_chunk_table(first, per, n)
-        assert top <= cap, (first, per, n, top)
-    assert lib.ldpc_hip_selftest_chunk_table(0, cap + 1, 1) == 2**64 - 1  # larger than the table: refused, not overrun
+def test_chunk_state_ring_bookkeeping(lib):
+    """Host replay (on a symbolic table: each row records which chunk's state it holds) of the noise stream's chunk-state
+    ring, libldpc_amd/csrc/mtstates.hpp: far more sequential requests than the ring has rows — a long Monte-Carlo run of
+    one-chunk batches (BSC/BEC batches, the encoder's info stream), headline-sized batches, requests as wide as the
+    window — must leave every requested chunk with a valid row, never read a row that holds nothing, and in steady state
+    cost as many jump-ahead tasks as chunks were consumed (no doubling bursts)."""
+    win, bad = 2048, 2**64 - 1
+    for first, per, n in [(0, 1, 3 * 4096 + 7), (0, 2, 2 * 4096), (0, 82, 600), (5, 64, 2000), (0, win, 9), (123456, 1, win + 50),
+                          (0, 7, 4000), (4095, 1, 10), (4096, 1, 10), (0, win - 1, 7), (10**12 + 3, 83, 100)]:
+        tasks = lib.ldpc_hip_selftest_chunk_table(first, per, n, 0)
+        assert tasks != bad, (first, per, n)
+        assert tasks <= per * n + 64 + 12, (first, per, n, tasks)  # + the seek to `first` (one task per set bit)
+    assert lib.ldpc_hip_selftest_chunk_table(0, win + 1, 1, 0) == bad  # wider than the window: refused, not overrun
+    # a rank of a sharded BSC / BEC stream: equal requests a fixed distance apart -> one launch per request, whatever the gap
+    per, n = 65, 80
+    for world in (2, 4, 8, 64):
+        for rank in (0, world - 1):
+            tasks = lib.ldpc_hip_selftest_chunk_table(rank * per, per, n, per * (world - 1))
+            assert tasks != bad and tasks <= per * n + 200, (world, rank, tasks)
+
+
+def test_sharded_state_table_costs_the_same_for_every_world_size(lib):
+    """The table of a rank of a sharded AWGN stream (StridedTable): after the first step every step is ONE launch of
+    piece + 1 jump-ahead tasks, whatever the world size and rank (round-2 VERDICT: the contiguous table made every rank
+    compute the states of all ranks' chunks)."""
+    bad = 2**64 - 1
+    for m in (1, 2, 82):
+        for world in (1, 2, 3, 4, 8, 64):
+            for rank in sorted({0, world // 2, world - 1}):
+                launches = ct.c_uint64(0)
+                tasks = lib.ldpc_hip_selftest_shard_table(world, rank, m, 40, ct.byref(launches))
+                assert tasks != bad, (m, world, rank)
+                assert tasks == (m + 1) * 39 and launches.value == 39, (m, world, rank, tasks, launches.value)
 
 
 def test_struct_layouts_match_reference_abi():

@@ -40,11 +40,11 @@ def test_shm_communicator_all_gather(world):
             assert np.array_equal(got[r][k], want), (k, r)
 
 
-def _shard_worker(rank, world, name, case, q):
+def _shard_worker(rank, world, name, case, q, code_file=None):
     sys.path.insert(0, ROOT)
     import libldpc_amd
     chan, x, seed, target, steps, decoding, gen = case
-    dec = libldpc_amd.HipDecoder(orc.H_TXT, orc.G_TXT if gen else "")
+    dec = libldpc_amd.HipDecoder(code_file or orc.H_TXT, orc.G_TXT if gen else "")
     dec.set_bec_compat(True)
     comm = libldpc_amd.Comm(rank, world, shm_name=name)
     dec.stream_begin(chan, seed, x)
@@ -91,6 +91,69 @@ def test_sharded_frames_keep_their_results(case, world):
         assert nxt == step0[0] + step0[1]
         pos = nxt
     assert total >= target * steps * 0.9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [("AWGN", 2.0, 0, 600, 3, "BP", False), ("AWGN", 1.2, 3, 50, 2, "BP_MS", False),
+                                  ("BEC", 0.42, 1, 500, 2, "BP", False), ("BSC", 0.06, 2, 301, 2, "BP", False)])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_frames_keep_their_results_config4_code(case, world, h8k_file):
+    """The same on the code BASELINE.json shards (config 4: (3,6)-regular n=8192, register-resident decoder, one
+    workgroup per CU): pieces of three chunks and of one chunk per rank, AWGN / BEC / BSC."""
+    import libldpc_amd
+    chan, x, seed, target, steps, decoding, gen = case
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"/ldpc_amd_test_{os.getpid()}_k{world}"
+    ps = [ctx.Process(target=_shard_worker, args=(r, world, name, case, q, h8k_file)) for r in range(world)]
+    [p.start() for p in ps]
+    got = dict(q.get(timeout=300) for _ in range(world))
+    [p.join(timeout=60) for p in ps]
+    total = got[0][-1][0][0] + got[0][-1][0][1]
+    dec = libldpc_amd.HipDecoder(h8k_file)
+    dec.stream_begin(chan, seed, x)
+    ref = dec.stream_decode(total, decoding=decoding)
+    pos = 0
+    for s in range(steps):
+        step0 = got[0][s][0]
+        assert step0[0] == pos
+        nxt = step0[0]
+        for r in range(world):
+            step, it, be = got[r][s]
+            assert step[:2] == step0[:2] and step[2] == nxt
+            assert np.array_equal(it, ref["iters"][step[2]:step[2] + step[3]]), (s, r)
+            assert np.array_equal(be, ref["bit_errors"][step[2]:step[2] + step[3]]), (s, r)
+            nxt += step[3]
+        assert nxt == step0[0] + step0[1]
+        pos = nxt
+    assert total >= target * steps * 0.8
+
+
+def test_sharded_step_failure_reaches_every_rank():
+    """A rank that fails inside a sharded step publishes a status word in the step's all-gather: every rank raises from
+    the same call instead of waiting in the next collective (round-2 ADVICE).  CPU: the engine is never reached — an
+    unusable device makes the step fail on every rank, and the ranks must all return, promptly."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"/ldpc_amd_test_{os.getpid()}_fail"
+    ps = [ctx.Process(target=_failing_worker, args=(r, 2, name, q)) for r in range(2)]
+    [p.start() for p in ps]
+    got = dict(q.get(timeout=120) for _ in range(2))
+    [p.join(timeout=60) for p in ps]
+    assert all("sharded step failed" in got[r] or "HIP" in got[r] or "device" in got[r] for r in range(2)), got
+
+
+def _failing_worker(rank, world, name, q):
+    sys.path.insert(0, ROOT)
+    import libldpc_amd
+    dec = libldpc_amd.HipDecoder(orc.H_TXT, device=0 if rank == 0 else 7)  # rank 1's device does not exist anywhere we test
+    comm = libldpc_amd.Comm(rank, world, shm_name=name)
+    try:
+        dec.stream_begin("AWGN", 0, -4.0)
+        dec.stream_decode_sharded(comm, 1000)
+        q.put((rank, "no error"))
+    except Exception as e:
+        q.put((rank, str(e)))
 
 
 def _cli(args, out, extra=()):

@@ -182,7 +182,7 @@ def cpu_baseline(w, budget_s=18.0):
     cores = os.cpu_count() or 1
     ref = os.path.join(ROOT, "oracle", "_ref", "ldpcsim_ref")
     d = workloads.code_dims(w)
-    guess = {"1": 700, "2": 700, "2f": 700, "2n": 230, "3": 1100, "4": 90, "4n": 13, "5": 500, "5bec": 4300}[w["key"]]  # frames/s, one core
+    guess = {"1": 700, "2": 700, "2f": 700, "2l": 700, "2h": 700, "2n": 230, "3": 1100, "4": 90, "4n": 13, "5": 500, "5bec": 4300}[w["key"]]  # frames/s, one core
     out = os.path.join(tempfile.gettempdir(), f"ldpc_ref_{os.getpid()}.txt")
 
     def run_ref(frames, threads):
@@ -295,7 +295,7 @@ def run_rank(args, w):
     dec = libldpc_amd.HipDecoder(workloads.code_path(w), device=local_rank)
     dec.set_profiling(True)
     dec.set_bec_compat(w.get("bec_compat", False))
-    dec.set_fast_mode(w.get("fast", False))
+    dec.set_fast_mode(int(w.get("fast", 0)))
     stream = torch.cuda.current_stream().cuda_stream
     dev = torch.device("cuda", local_rank)
     cap = dec.shard_capacity(B * world, world) if world > 1 else B
@@ -492,7 +492,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8" if w["channel"] == "BEC" else ("f32 (non-parity fast mode)" if w.get("fast") else "f64"),
+            "dtype": "u8" if w["channel"] == "BEC" else ({1: "f32 (non-parity fast mode)", 2: "f32 (non-parity layered mode)", 3: "f16 messages / f32 totals (non-parity layered mode)"}[int(w["fast"])] if w.get("fast") else "f64"),
             "data": "synthetic",
             "config": {"workload": w["name"], "baseline_config": args.config, "frames_per_step": m["frames"] // K,
                        "parallelism": f"frame-shard x{world}", "code": d},

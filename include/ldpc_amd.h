@@ -111,11 +111,17 @@ const char *ldpc_hip_describe(ldpc_hip_ctx *ctx);
 /* BEC: 1 = reproduce the reference's out-of-bounds read for erased degree-1 variable nodes
    (they emit 0); 0 (default) = defined semantics, they emit an erasure */
 void ldpc_hip_set_bec_compat(ldpc_hip_ctx *ctx, int compat);
-/* 1 = NON-PARITY fast mode for sum-product decoding ("BP"): binary32 messages, LLRs clipped to +-27.7, hardware
-   reciprocal / log2 / exp2 (libldpc_amd/csrc/kernels_fast.hip).  Error rates differ from the reference's within what
-   profiles/ reports; iteration counts and decisions are not the reference's.  Off by default; min-sum and BEC ignore it.
-   The reference has no such mode in src/ (its legacy gpu/ simulator uses single precision, gpu/ldpc/ldpc.h). */
-void ldpc_hip_set_fast_mode(ldpc_hip_ctx *ctx, int on);
+/* NON-PARITY modes for sum-product decoding ("BP"), off (0) by default and never chosen by the library itself; min-sum and
+   BEC ignore them.  Error rates differ from the reference's within what profiles/ reports; iteration counts and decisions
+   are not the reference's.
+     1  flooding schedule, binary32 messages, LLRs clipped to +-27.7, hardware reciprocal / log2 / exp2
+        (libldpc_amd/csrc/kernels_fast.hip)
+     2  LAYERED (row-serial) schedule, binary32 check-to-variable messages: one wavefront per frame, a sweep is a sequence
+        of conflict-free steps of up to 64 check nodes (libldpc_amd/csrc/kernels_layered.hip)
+     3  the same with binary16 check-to-variable messages
+   The reference has no such modes in src/ (its legacy gpu/ simulator uses single precision and processes H in layers,
+   gpu/ldpc/ldpc.h, gpu/ldpc/ldpc.cpp:111-138: ideas only). */
+void ldpc_hip_set_fast_mode(ldpc_hip_ctx *ctx, int mode);
 
 /* decode n frames of given LLRs llr_in[n][nc] (column order, device or host). 0 on success. */
 int ldpc_hip_decode_batch(ldpc_hip_ctx *ctx, decoder_param dec, uint64_t n, const double *llr_in,

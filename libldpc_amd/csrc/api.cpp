@@ -263,7 +263,7 @@ const char *ldpc_hip_describe(ldpc_hip_ctx *ctx)
 }
 
 void ldpc_hip_set_bec_compat(ldpc_hip_ctx *ctx, int compat) { ctx->eng->bec_deg1_compat = compat != 0; }
-void ldpc_hip_set_fast_mode(ldpc_hip_ctx *ctx, int on) { ctx->eng->fast_mode = on != 0; }
+void ldpc_hip_set_fast_mode(ldpc_hip_ctx *ctx, int mode) { ctx->eng->fast_mode = mode < 0 || mode > 3 ? 0 : mode; }
 
 int ldpc_hip_decode_batch(ldpc_hip_ctx *ctx, decoder_param dec, uint64_t n, const double *llr_in,
                           const ldpc_hip_out *out, void *hip_stream)

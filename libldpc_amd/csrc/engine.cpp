@@ -223,7 +223,7 @@ void MtDevice::apply(const std::vector<StateOp> &ops, uint64_t *table, void *str
                   "state copy");
             break;
         case StateOp::kJump:
-            check(launch_mt_jump(table, op.mod, op.src, op.dst, device_poly(op.stride, stream), op.n, s), "mt_jump");
+            check(launch_mt_jump(table, op.mod, op.src, op.dst, device_poly(op.stride, stream), op.n, jump_pack_, s), "mt_jump");
             jump_tasks_ += op.n;
             break;
         }
@@ -268,7 +268,7 @@ const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream,
         const uint64_t need = (first + count - c_lo * cw + kMtWords - 1) / kMtWords * kMtWords;
         words = static_cast<uint32_t>(std::min<uint64_t>(need, cw));
     }
-    check(launch_mt_generate(st.ring(), MtDevice::ring_rows(), row, raw, n, words, n == 1 ? 1 : pack_, s), "mt_generate");
+    check(launch_mt_generate(st.ring(), MtDevice::ring_rows(), row, raw, n, words, words, n == 1 ? 1 : pack_, s), "mt_generate");
     return raw + (first - c_lo * cw);
 }
 
@@ -300,7 +300,7 @@ Engine::Engine(const std::string &pc_file, const std::string &gen_file, int devi
         // a register-resident decode workgroup owns its CU: keep the noise generator of the next batch, which runs
         // beside it, on a quarter of the CUs (config 4: 4.89 -> 4.62 ms per step)
         if (reg_plan_.ok)
-            noise_.set_pack(4);
+            noise_.set_pack(4), noise_.st.set_jump_pack(3);
     }
 }
 
@@ -509,12 +509,54 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
     prof_mark(0, s);
     if (fast_mode && !p.min_sum)
     {
-        // the caller asked for the non-parity binary32 sum-product; never chosen by itself
-        if (!fast_mode_supported(dev_, plan_.max_cn_degree) || plan_.has_isolated_vn)
-            throw std::runtime_error("fast mode: this code is outside what the binary32 kernel takes (check nodes up to degree 8, "
-                                     "nc <= 8192, LDS-resident, no isolated variable node)");
-        a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nc));
-        check(launch_decode_fast(a, plan_.max_cn_degree, s), "decode (fast mode, binary32)");
+        // the caller asked for a non-parity mode; never chosen by itself
+        if (fast_mode == 1)
+        {
+            if (!fast_mode_supported(dev_, plan_.max_cn_degree) || plan_.has_isolated_vn)
+                throw std::runtime_error("fast mode: this code is outside what the binary32 kernel takes (check nodes up to degree 8, "
+                                         "nc <= 8192, LDS-resident, no isolated variable node)");
+            a.ws_hb = static_cast<uint8_t *>(ws_hb_.reserve(n * nc));
+            check(launch_decode_fast(a, plan_.max_cn_degree, s), "decode (fast mode, binary32)");
+        }
+        else
+        {
+            if (!layer_plan_.ok && layer_plan_.steps.empty())
+            {
+                layer_plan_ = build_layer_plan(*code_, plan_);
+                if (layer_plan_.ok)
+                {
+                    std::vector<uint32_t> st;
+                    for (const LayerStep &l : layer_plan_.steps)
+                        st.push_back(l.off), st.push_back(static_cast<uint32_t>(l.count) | static_cast<uint32_t>(l.degree) << 16);
+                    // the steps' neighbour tables as the kernel fetches them: four words per lane, two VN ranks per word
+                    std::vector<uint32_t> vn4(layer_plan_.steps.size() * 4 * kWaveSize, 0);
+                    for (size_t si = 0; si < layer_plan_.steps.size(); ++si)
+                        for (int j = 0; j < layer_plan_.steps[si].degree; ++j)
+                            for (int l = 0; l < kWaveSize; ++l)
+                                vn4[(si * 4 + j / 2) * kWaveSize + l] |=
+                                    static_cast<uint32_t>(layer_plan_.vn[layer_plan_.steps[si].off + static_cast<size_t>(j) * kWaveSize + l]) << (16 * (j & 1));
+                    void *d_steps = nullptr, *d_vn = nullptr;
+                    check(hipMalloc(&d_steps, st.size() * 4), "hipMalloc layer plan");
+                    owned_.push_back(d_steps);
+                    check(hipMalloc(&d_vn, vn4.size() * 4), "hipMalloc layer plan");
+                    owned_.push_back(d_vn);
+                    check(hipMemcpy(d_steps, st.data(), st.size() * 4, hipMemcpyHostToDevice), "upload layer plan");
+                    check(hipMemcpy(d_vn, vn4.data(), vn4.size() * 4, hipMemcpyHostToDevice), "upload layer plan");
+                    dev_layer_.steps = static_cast<const uint32_t *>(d_steps);
+                    dev_layer_.vn4 = static_cast<const uint32_t *>(d_vn);
+                    dev_layer_.n_steps = static_cast<uint32_t>(layer_plan_.steps.size());
+                    dev_layer_.slots = layer_plan_.slots;
+                    const size_t tot_bytes = 4 * ((nc + 3) & ~size_t(3));
+                    dev_layer_.region_bytes = static_cast<uint32_t>((std::max(8 * nc, tot_bytes + 4 * size_t(layer_plan_.slots)) + 15) & ~size_t(15));
+                    dev_layer_.region_bytes_half = static_cast<uint32_t>((std::max(8 * nc, tot_bytes + 2 * size_t(layer_plan_.slots)) + 15) & ~size_t(15));
+                }
+            }
+            const bool half = fast_mode == 3;
+            if (!layer_plan_.ok || plan_.has_isolated_vn || (half ? dev_layer_.region_bytes_half : dev_layer_.region_bytes) > 160 * 1024)
+                throw std::runtime_error("layered mode: this code is outside what the layered kernel takes (check nodes of degree 2..8, at "
+                                         "most 65535 columns, totals and messages of one frame within 160 KB of LDS, no isolated variable node)");
+            check(launch_decode_layered(a, dev_layer_, half, s), half ? "decode (layered, binary16 messages)" : "decode (layered, binary32 messages)");
+        }
         prof_mark(0, s);
         if (a.mode == kModeAwgn && a.pairs_buffer >= 0 && ev_pairs_free_[a.pairs_buffer])
         {
@@ -897,7 +939,8 @@ Engine::NoisePass Engine::noise_pass(uint64_t chunk, uint32_t full, uint32_t las
         na.ring = st.ring();
         na.ring_rows = MtDevice::ring_rows();
     }
-    np.slabs = write_normals ? static_cast<uint64_t *>(slabs_[buf].reserve(8 * slab_words * np.n_slabs)) : nullptr;
+    // (two slabs of slack: the number of chunks a batch spans varies by one, and growing a buffer means freeing it first)
+    np.slabs = write_normals ? static_cast<uint64_t *>(slabs_[buf].reserve(8 * slab_words * (np.n_slabs + 2))) : nullptr;
     // (a counting pass must not touch the slab table a decode launch in flight may still read)
     np.cum = static_cast<uint64_t *>((write_normals ? slab_cum_[buf] : nz_cum_skip_).reserve(8 * (static_cast<size_t>(np.n_slabs) + 1)));
     uint32_t *counts = static_cast<uint32_t *>(nz_counts_.reserve(4 * static_cast<size_t>(np.n_slabs)));
@@ -908,25 +951,12 @@ Engine::NoisePass Engine::noise_pass(uint64_t chunk, uint32_t full, uint32_t las
     na.write_normals = write_normals ? 1 : 0;
     na.locate_chunk = 0xFFFFFFFFu;
     na.pack = noise_.pack();
-    na.raw = static_cast<uint64_t *>(nz_raw_.reserve(8 * st.chunk_words() * std::max<uint32_t>(full, 1)));
-    na.lookback = static_cast<uint64_t *>(nz_lookback_.reserve(8 * normals_lookback_words(std::max<uint32_t>(full, 1), st.chunk_blocks())));
-    if (full)
-    {
-        na.n_chunks = full;
-        na.blocks = st.chunk_blocks();
-        check(launch_mt_normals(na, s), "mt_normals");
-    }
-    if (last_blocks)
-    {
-        NormalsArgs nl = na;
-        nl.first_row = (na.first_row + full) % na.ring_rows;
-        nl.n_chunks = 1;
-        nl.blocks = last_blocks;
-        nl.slabs = np.slabs ? np.slabs + slab_words * full : nullptr;
-        nl.counts = counts + full;
-        nl.pack = 1;
-        check(launch_mt_normals(nl, s), "mt_normals (prefix)");
-    }
+    na.raw = static_cast<uint64_t *>(nz_raw_.reserve(8 * st.chunk_words() * (np.n_slabs + 2)));
+    na.lookback = static_cast<uint64_t *>(nz_lookback_.reserve(8 * normals_lookback_words(np.n_slabs + 2, st.chunk_blocks())));
+    na.n_chunks = np.n_slabs;
+    na.blocks = st.chunk_blocks();
+    na.last_blocks = last_blocks ? last_blocks : st.chunk_blocks(); // (the prefix chunk rides in the same two launches)
+    check(launch_mt_normals(na, s), "mt_normals");
     check(launch_normals_finish(counts, np.n_slabs, n_piece, full, need, target, np.cum, res, s), "normals_finish");
     check(hipMemcpyAsync(&np.res, res, sizeof np.res, hipMemcpyDeviceToHost, s), "noise result");
     const auto t0 = std::chrono::steady_clock::now();
@@ -1032,7 +1062,7 @@ uint64_t Engine::stream_raw_draws()
     na.ring = st.ring();
     na.ring_rows = MtDevice::ring_rows();
     na.n_chunks = 1;
-    na.blocks = st.chunk_blocks();
+    na.blocks = na.last_blocks = st.chunk_blocks();
     na.slab_words = 2 * st.chunk_trials();
     na.counts = static_cast<uint32_t *>(nz_counts_.reserve(4));
     na.write_normals = 0;

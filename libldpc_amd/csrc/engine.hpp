@@ -98,6 +98,7 @@ class MtDevice
     uint64_t *ensure_strided(uint64_t first, uint32_t n, uint64_t stride, void *stream);
     static constexpr uint32_t strided_rows() { return StridedTable::kMaxRows + 2; }
     uint64_t jump_tasks() const { return jump_tasks_; } // jump-ahead tasks launched so far (tools/shard_probe.py)
+    void set_jump_pack(int tasks_per_workgroup) { jump_pack_ = tasks_per_workgroup; } // kernels.hpp launch_mt_jump
 
   private:
     void apply(const std::vector<StateOp> &ops, uint64_t *table, void *stream);
@@ -110,6 +111,7 @@ class MtDevice
     DeviceBuffer ring_buf_, strided_buf_;
     std::vector<std::pair<uint64_t, void *>> polys_; // (stride in chunks, device copy)
     uint64_t jump_tasks_ = 0;
+    int jump_pack_ = 1;
 };
 
 // Raw words of one mt19937_64(seed) stream (BSC / BEC draws, info words, ldpc_hip_mt64).
@@ -143,8 +145,9 @@ class Engine
     const Reg2Plan &reg2_plan() const { return reg2_plan_; }
     int device() const { return device_; }
     bool bec_deg1_compat = false;
-    // opt-in NON-PARITY fast mode: sum-product with binary32 messages (kernels_fast.hip); off by default
-    bool fast_mode = false;
+    // opt-in NON-PARITY modes, off (0) by default and never chosen by the library: 1 = flooding sum-product with binary32
+    // messages (kernels_fast.hip); 2 / 3 = LAYERED sum-product with binary32 / binary16 messages (kernels_layered.hip)
+    int fast_mode = 0;
 
     // ---- decode given LLRs (C-ABI decode(), shared.cpp:47-65, batched) ----
     void decode_llr(const DecParams &p, uint64_t n, const double *llr_in, const BatchOut &out, void *stream);
@@ -223,6 +226,8 @@ class Engine
     Plan plan_;
     RegPlan reg_plan_;
     Reg2Plan reg2_plan_;
+    LayerPlan layer_plan_;
+    DevLayerPlan dev_layer_{};
     DevPlan dev_{};
     DevRegPlan dev_reg_{};
     DevReg2Plan dev_reg2_{};

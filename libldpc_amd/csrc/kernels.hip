@@ -1015,7 +1015,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         {
             PHASE_START
             uint32_t bad = 0;
-            constexpr bool SH = !HANDOVER; // early termination: shared-reciprocal check nodes (detmath.h)
+            // LDS-resident decoder with early termination: shared-reciprocal check nodes (detmath.h; the oracle applies the
+            // same rule, a property of the code)
+            constexpr bool SH = LDS_RESIDENT && !HANDOVER;
             // blocks two at a time where they match (plan.cpp deals each wave's blocks in degree order); both
             // descriptors arrive with one scalar load (plan.cpp, cn_work_desc)
             for (int w = 0; w < P.cn_work_stride; w += 2)
@@ -1367,8 +1369,11 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
     decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO>(a);
 }
 
+#ifndef LDPC_AMD_HANDOVER_WAVES
+#define LDPC_AMD_HANDOVER_WAVES 5
+#endif
 template <bool WANT_LLR, int MAXD, int LLR_MODE>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void decode_kernel_handover(const DecodeArgs a)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(LDPC_AMD_HANDOVER_WAVES, 5))) void decode_kernel_handover(const DecodeArgs a)
 {
     decode_body<false, WANT_LLR, true, MAXD, LLR_MODE, true, true>(a);
 }

@@ -158,6 +158,15 @@ int launch_decode_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, 
 // opt-in non-parity fast mode (kernels_fast.hip): sum-product with binary32 messages; a.ws_hb [n][nc] must be set
 bool fast_mode_supported(const DevPlan &p, int max_cn_degree);
 int launch_decode_fast(const DecodeArgs &a, int max_cn_degree, void *stream);
+// opt-in non-parity layered schedule (kernels_layered.hip): device copy of LayerPlan (plan.hpp)
+struct DevLayerPlan
+{
+    const uint32_t *steps; // [n_steps][2]: offset into vn / the message array, count | degree << 16
+    const uint32_t *vn4;   // [(step * 4 + w) * 64 + lane]: VN ranks of edges 2w, 2w+1 of the step's lane-th check node (16 bits each)
+    uint32_t n_steps, slots;
+    uint32_t region_bytes, region_bytes_half; // LDS per frame with binary32 / binary16 messages
+};
+int launch_decode_layered(const DecodeArgs &a, const DevLayerPlan &L, bool half_messages, void *stream);
 int launch_bec(const BecArgs &a, void *stream);
 
 // ---- mt19937_64 on the device ----
@@ -165,15 +174,17 @@ constexpr int kMtN = 312;
 constexpr uint32_t kBlockTrials = kMtN / 2; // one twist block of 312 words = 156 polar trials
 // Chunk start states live in a RING of ring_rows rows of 312 words: chunk i of a launch starts from row
 // (first_row + i) % ring_rows (first_row < ring_rows, n <= ring_rows).
-// Raw (tempered) outputs: chunk i writes out[i * chunk_words ..), chunk_words a multiple of 312.  pack: chunks per
-// workgroup (1, or 4 to keep the generator on a quarter of the compute units beside decode kernels that own a whole CU).
+// Raw (tempered) outputs: chunk i writes out[i * chunk_words ..), chunk_words a multiple of 312; the LAST chunk of the
+// launch generates last_words <= chunk_words only (a prefix, in the same launch).  pack: chunks per workgroup (1, or 4 to
+// keep the generator on a quarter of the compute units beside decode kernels that own a whole CU).
 int launch_mt_generate(const uint64_t *ring, uint32_t ring_rows, uint32_t first_row, uint64_t *out, uint32_t n_chunks,
-                       uint32_t chunk_words, int pack, void *stream);
+                       uint32_t chunk_words, uint32_t last_words, int pack, void *stream);
 // Jump: row (dst_first + t) % ring_rows = row (src_first + t) % ring_rows advanced by the polynomial `poly` (19937
 // coefficient bits, kJumpPolyWords words: 312 + zero padding), t < n_tasks.  A task reads its source row before it writes,
 // so src_first == dst_first (in place) is allowed; otherwise the two row ranges must not overlap.
+// pack: tasks per workgroup (1, or 3 beside decode kernels that own a whole CU).
 int launch_mt_jump(uint64_t *ring, uint32_t ring_rows, uint32_t src_first, uint32_t dst_first, const uint64_t *poly,
-                   uint32_t n_tasks, void *stream);
+                   uint32_t n_tasks, int pack, void *stream);
 constexpr uint32_t kJumpPolyWords = 320;
 
 // The AWGN noise generator: chunks of the raw stream -> the normal variates the reference's normal_distribution would
@@ -187,7 +198,8 @@ struct NormalsArgs
     const uint64_t *ring;
     uint32_t ring_rows, first_row;
     uint32_t n_chunks;
-    uint32_t blocks;      // twist blocks (312 words = 156 trials each) every chunk of this launch generates
+    uint32_t blocks;      // twist blocks (312 words = 156 trials each) a chunk holds
+    uint32_t last_blocks; // ... and how many of them the launch's LAST chunk generates (a prefix; == blocks: all of it)
     int pack;             // generator: chunks per workgroup (launch_mt_generate)
     uint64_t *raw;        // scratch: n_chunks * 312 * blocks words
     uint64_t *lookback;   // scratch: n_chunks * (ceil(156 * blocks / kSlabBlock) + 1) words (zeroed by the launcher)

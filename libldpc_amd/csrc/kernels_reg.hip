@@ -29,10 +29,10 @@ namespace ldpc_amd
 namespace
 {
 
-// RATIO (always with early termination here): nodes of degree 3 and 4 in the shared-reciprocal form (detmath.h); a
-// denominator product beyond its range marks the frame as escaped
+// (the shared-reciprocal form of detmath.h belongs to the LDS-resident decoder: its range check rides on that kernel's
+// check-node-first loop; here every output is divided separately)
 template <bool MINSUM, bool RATIO, int MAXD>
-__device__ __forceinline__ void cn_regs(double (&m)[MAXD], int degree, uint32_t &escaped)
+__device__ __forceinline__ void cn_regs(double (&m)[MAXD], int degree)
 {
     // wave-uniform degree: one fully unrolled recursion per width
 #define LDPC_CASE(D)                         \
@@ -41,7 +41,7 @@ __device__ __forceinline__ void cn_regs(double (&m)[MAXD], int degree, uint32_t 
         double v[D];                         \
         _Pragma("unroll") for (int j = 0; j < D; ++j) v[j] = m[j]; \
         if constexpr (RATIO)                 \
-            cn_ratio<D, true>(v, &escaped);  \
+            cn_ratio<D>(v);                  \
         else                                 \
             cn_core<D, MINSUM>(v);           \
         _Pragma("unroll") for (int j = 0; j < D; ++j) m[j] = v[j]; \
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
         // ---- CN pass (decoder.cpp:25-45), entirely in registers ----
         // (a fold expression, not a loop: every m[k] must be a compile-time register row)
         [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
-            ((have[Ks] ? cn_regs<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks], escaped) : void()), ...);
+            ((have[Ks] ? cn_regs<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks]) : void()), ...);
         }(std::make_integer_sequence<int, KC>{});
 
         int par[KC];

@@ -41,10 +41,10 @@ namespace ldpc_amd
 namespace
 {
 
-// RATIO (always with early termination here): nodes of degree 3 and 4 in the shared-reciprocal form (detmath.h); a
-// denominator product beyond its range marks the frame as escaped
+// (the shared-reciprocal form of detmath.h belongs to the LDS-resident decoder: its range check rides on that kernel's
+// check-node-first loop; here every output is divided separately)
 template <bool MINSUM, bool RATIO, int MAXD>
-__device__ __forceinline__ void cn_regs2(double (&m)[MAXD], int degree, uint32_t &escaped)
+__device__ __forceinline__ void cn_regs2(double (&m)[MAXD], int degree)
 {
     // wave-uniform degree: one fully unrolled recursion per width
 #define LDPC_CASE(D)                                                \
@@ -53,7 +53,7 @@ __device__ __forceinline__ void cn_regs2(double (&m)[MAXD], int degree, uint32_t
         double v[D];                                                \
         _Pragma("unroll") for (int j = 0; j < D; ++j) v[j] = m[j];  \
         if constexpr (RATIO)                                        \
-            cn_ratio<D, true>(v, &escaped);                         \
+            cn_ratio<D>(v);                                         \
         else                                                        \
             cn_core<D, MINSUM>(v);                                  \
         _Pragma("unroll") for (int j = 0; j < D; ++j) m[j] = v[j];  \
@@ -318,10 +318,10 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
                  if constexpr (!UCN)
                  {
                      if (deg[Ks] >= 2)
-                         cn_regs2<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks], escaped);
+                         cn_regs2<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks]);
                  }
                  else if constexpr (RATIO)
-                     cn_ratio<MAXD, true>(m[Ks], &escaped);
+                     cn_ratio<MAXD>(m[Ks]);
                  else
                      cn_core<MAXD, MINSUM>(m[Ks]);
              }()),

@@ -442,4 +442,64 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
     return r;
 }
 
+// Steps of the layered schedule: check nodes in file order within each degree, each put into the first step of its degree
+// that has a free lane and none of its variable nodes yet (greedy; a variable node of degree d forces its d check nodes
+// into d different steps).  Steps are ordered by the file position of their first check node, so a sweep still walks H
+// roughly top to bottom.
+LayerPlan build_layer_plan(const LdpcCode &code, const Plan &plan)
+{
+    LayerPlan L;
+    const SparseGF2 &H = code.H;
+    if (H.cols > 0xFFFF || code.max_cn_degree() > kMaxLdsCnDegree || code.min_cn_degree() < 2)
+        return L;
+    struct Open
+    {
+        int degree;
+        std::vector<int> rows;
+        std::vector<uint8_t> used; // per column
+    };
+    std::vector<Open> open;
+    for (int i = 0; i < H.rows; ++i)
+    {
+        const int deg = H.rptr[i + 1] - H.rptr[i];
+        Open *dst = nullptr;
+        for (Open &o : open)
+        {
+            if (o.degree != deg || static_cast<int>(o.rows.size()) >= kWaveSize)
+                continue;
+            bool clash = false;
+            for (int p = H.rptr[i]; p < H.rptr[i + 1] && !clash; ++p)
+                clash = o.used[H.rcol[p]] != 0;
+            if (!clash)
+            {
+                dst = &o;
+                break;
+            }
+        }
+        if (!dst)
+        {
+            open.push_back({deg, {}, std::vector<uint8_t>(H.cols, 0)});
+            dst = &open.back();
+        }
+        dst->rows.push_back(i);
+        for (int p = H.rptr[i]; p < H.rptr[i + 1]; ++p)
+            dst->used[H.rcol[p]] = 1;
+    }
+    for (const Open &o : open)
+    {
+        LayerStep st{static_cast<uint32_t>(L.vn.size()), static_cast<uint16_t>(o.rows.size()), static_cast<uint16_t>(o.degree)};
+        L.vn.resize(L.vn.size() + static_cast<size_t>(o.degree) * kWaveSize, 0);
+        for (size_t l = 0; l < o.rows.size(); ++l)
+        {
+            const int i = o.rows[l];
+            for (int j = 0; j < o.degree; ++j)
+                L.vn[st.off + static_cast<size_t>(j) * kWaveSize + l] = static_cast<uint16_t>(plan.col_rank[H.rcol[H.rptr[i] + j]]);
+        }
+        L.steps.push_back(st);
+    }
+    L.slots = static_cast<uint32_t>(L.vn.size());
+    L.ok = !L.steps.empty();
+    return L;
+}
+
 } // namespace ldpc_amd

@@ -157,6 +157,24 @@ struct Reg2Plan
     std::vector<uint32_t> vn_rank;      // [(i*(nt/64) + wave)*64 + lane] VN rank of the Plan (kNoSlot = none)
 };
 
+// ---- layered schedule of the opt-in non-parity modes (kernels_layered.hip) -----------------------------------------
+// A sweep over the check nodes is a sequence of STEPS; a step is up to 64 check nodes of equal degree no two of which
+// share a variable node (one wave = one frame, one lane = one check node of the step).  Edge j of lane l of a step sits
+// at offset off + j * 64 + l of the vn table (VN rank of the Plan) and of the frame's message array.
+struct LayerStep
+{
+    uint32_t off;
+    uint16_t count, degree;
+};
+struct LayerPlan
+{
+    bool ok = false;
+    std::vector<LayerStep> steps;
+    std::vector<uint16_t> vn;
+    uint32_t slots = 0; // entries of the message array (sum of 64 * degree over the steps)
+};
+LayerPlan build_layer_plan(const LdpcCode &code, const Plan &plan);
+
 Plan build_plan(const LdpcCode &code);
 // plan for the decode_reg2_kernel<nt, kc, maxd, nv0, nv1> instantiation; ok = false when the code does not fit it
 Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc, int maxd, int nv0, int nv1);

@@ -71,13 +71,13 @@ __device__ __forceinline__ uint32_t ring_index(uint32_t rows, uint32_t first, ui
 
 template <int kGenChunks>
 __global__ __launch_bounds__(kGenThreads *kGenChunks) void mt_generate_kernel(const uint64_t *ring, uint32_t ring_rows, uint32_t first_row,
-                                                                              uint64_t *out, uint32_t chunk_words, uint32_t n_chunks)
+                                                                              uint64_t *out, uint32_t chunk_words, uint32_t last_words,
+                                                                              uint32_t n_chunks)
 {
     __shared__ uint64_t xs[kGenChunks][kMtN];
     const int t = threadIdx.x % kGenThreads, sub = threadIdx.x / kGenThreads;
     const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kGenChunks + sub;
     const bool live = c < n_chunks; // (the last workgroup may hold fewer chunks; its idle waves still meet the barriers)
-    const bool act = live && t < 156;
     uint64_t *x = xs[sub];
     if (live)
     {
@@ -88,9 +88,12 @@ __global__ __launch_bounds__(kGenThreads *kGenChunks) void mt_generate_kernel(co
     __syncthreads();
     uint64_t *o = out + c * chunk_words;
     const uint32_t blocks = chunk_words / kMtN;
+    // the launch's last chunk may be a prefix (last_words <= chunk_words): its waves keep meeting the barriers
+    const uint32_t my_blocks = c + 1 == n_chunks ? last_words / kMtN : blocks;
     for (uint32_t b = 0; b < blocks; ++b)
     {
         uint64_t lo = 0, hi = 0, lo1 = 0, hi1 = 0;
+        const bool act = live && t < 156 && b < my_blocks;
         if (act)
         {
             lo = x[t], hi = x[t + 156];
@@ -126,41 +129,49 @@ __global__ __launch_bounds__(kGenThreads *kGenChunks) void mt_generate_kernel(co
 // consecutive words.  Wave 0 then regenerates the next block and the ring advances.  The taps of a stage
 // are taken eight at a time: eight independent LDS reads in flight, then eight XORs predicated on
 // wave-uniform coefficient bits.
-constexpr int kJumpThreads = 320;
+constexpr int kJumpThreads = 192;    // per task: thread i < 156 owns output words 2i and 2i+1; wave 0 also runs the generator
 constexpr int kJumpStages = 64;      // 64 * 312 = 19968 >= 19937 taps
 constexpr int kPolyWords = 320;      // 312 coefficient words + zero padding read by the last stage
 
-__global__ __launch_bounds__(kJumpThreads) void mt_jump_kernel(uint64_t *table, uint32_t ring_rows, uint32_t src_first,
-                                                               uint32_t dst_first, const uint64_t *poly)
+// kPack tasks per workgroup (their waves share nothing but the barriers): beside a decode kernel whose workgroup owns a
+// whole CU, every resident jump workgroup keeps a frame out for as long as it runs — three tasks in one workgroup hold
+// a third of the CUs for the same time.
+template <int kPack>
+__global__ __launch_bounds__(kJumpThreads *kPack) void mt_jump_kernel(uint64_t *table, uint32_t ring_rows, uint32_t src_first,
+                                                                      uint32_t dst_first, const uint64_t *poly, uint32_t n_tasks)
 {
-    const uint64_t *src = table + static_cast<size_t>(ring_index(ring_rows, src_first, blockIdx.x)) * kMtN;
-    uint64_t *dst = table + static_cast<size_t>(ring_index(ring_rows, dst_first, blockIdx.x)) * kMtN;
-    __shared__ uint64_t x[kMtN];        // generator state = newest block
-    __shared__ uint64_t ring[2 * kMtN];
+    __shared__ uint64_t xs[kPack][kMtN];                                  // generator state = newest block
+    __shared__ __attribute__((aligned(16))) uint64_t rings[kPack][2 * kMtN];
     __shared__ uint64_t g[kPolyWords];
-    const int tid = threadIdx.x;
-    for (int k = tid; k < kPolyWords; k += kJumpThreads)
+    const int tid = threadIdx.x % kJumpThreads, sub = threadIdx.x / kJumpThreads;
+    const uint32_t task = blockIdx.x * kPack + sub;
+    const bool live = task < n_tasks;
+    uint64_t *x = xs[sub], *ring = rings[sub];
+    const uint64_t *src = table + static_cast<size_t>(ring_index(ring_rows, src_first, live ? task : 0)) * kMtN;
+    uint64_t *dst = table + static_cast<size_t>(ring_index(ring_rows, dst_first, live ? task : 0)) * kMtN;
+    for (int k = threadIdx.x; k < kPolyWords; k += kJumpThreads * kPack)
         g[k] = poly[k];
-    if (tid < kMtN)
+    for (int k = tid; k < kMtN; k += kJumpThreads)
     {
-        uint64_t v = src[tid];
-        x[tid] = v;
-        ring[tid] = v;
+        const uint64_t v = src[k];
+        x[k] = v;
+        ring[k] = v;
     }
     __syncthreads();
     if (tid < 64)
         mt_regenerate(x, tid);
     __syncthreads();
-    if (tid < kMtN)
-        ring[kMtN + tid] = x[tid];
+    for (int k = tid; k < kMtN; k += kJumpThreads)
+        ring[kMtN + k] = x[k];
     __syncthreads();
 
-    uint64_t acc = 0;
+    uint64_t acc0 = 0, acc1 = 0;
     for (int b = 0; b < kJumpStages; ++b)
     {
-        if (tid < kMtN)
+        if (tid < kMtN / 2)
         {
             const int k0 = b * kMtN;
+            const uint64_t *rp = ring + 2 * tid; // 16-byte aligned: the eight taps' words for both outputs are nine consecutive words
             for (int kk = 0; kk < kMtN; kk += 8)
             {
                 // eight coefficient bits starting at k0 + kk (wave-uniform)
@@ -171,31 +182,33 @@ __global__ __launch_bounds__(kJumpThreads) void mt_jump_kernel(uint64_t *table, 
                 uint32_t bits = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(lo | hi))) & 0xFFu;
                 if (bits == 0)
                     continue;
-                uint64_t v[8];
+                uint64_t v[10];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v[j] = ring[kk + j + tid];
+                for (int j = 0; j < 4; ++j)
+                {
+                    const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(rp + kk + 2 * j);
+                    v[2 * j] = q.x, v[2 * j + 1] = q.y;
+                }
+                v[8] = rp[kk + 8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (bits >> j & 1)
-                        acc ^= v[j];
+                        acc0 ^= v[j], acc1 ^= v[j + 1];
             }
         }
         __syncthreads();
         // advance: block b+1 becomes the low half, wave 0 produces block b+2
         if (tid < 64)
             mt_regenerate(x, tid);
-        uint64_t up = tid < kMtN ? ring[kMtN + tid] : 0;
+        uint64_t up0 = ring[kMtN + tid], up1 = tid + kJumpThreads < kMtN ? ring[kMtN + tid + kJumpThreads] : 0;
         __syncthreads();
-        if (tid < kMtN)
-        {
-            ring[tid] = up;
-            ring[kMtN + tid] = x[tid];
-        }
+        ring[tid] = up0, ring[kMtN + tid] = x[tid];
+        if (tid + kJumpThreads < kMtN)
+            ring[tid + kJumpThreads] = up1, ring[kMtN + tid + kJumpThreads] = x[tid + kJumpThreads];
         __syncthreads();
     }
-    if (tid < kMtN)
-        dst[tid] = acc; // (the task's own source row was read into LDS at the start: in place is fine)
+    if (live && tid < kMtN / 2) // (the task's own source row was read into LDS at the start: in place is fine)
+        dst[2 * tid] = acc0, dst[2 * tid + 1] = acc1;
 }
 
 // ---- AWGN: raw chunk -> slab of normals -------------------------------------------------------------------------
@@ -209,7 +222,8 @@ constexpr unsigned long long kLbPrefix = 1ull << 63, kLbAggregate = 1ull << 62, 
 // publishes its own prefix): a single pass over the raw words, no counting launch before the compaction.  Workgroups take
 // their place in their chunk's line from a ticket counter, so a workgroup only ever waits for workgroups that started before it.
 // Phase 2: every accepted trial is written to the chunk's slab at its rank in stream order, as its two normals.
-__global__ __launch_bounds__(kSlabThreads) void polar_slab_kernel(NormalsArgs a, uint32_t trials, uint32_t blocks_per_chunk)
+__global__ __launch_bounds__(kSlabThreads) void polar_slab_kernel(NormalsArgs a, uint32_t trials_full, uint32_t trials_last,
+                                                                  uint32_t blocks_per_chunk)
 {
     constexpr int kWaves = kSlabThreads / 64;
     __shared__ unsigned long long ballot[kSlabIters * kWaves]; // accepted lanes of (it, wave): trials in ascending order
@@ -220,6 +234,11 @@ __global__ __launch_bounds__(kSlabThreads) void polar_slab_kernel(NormalsArgs a,
     // the workgroup's chunk is fixed by its index; its place in the chunk's line is a ticket of that chunk's counter (one
     // counter per chunk: a single counter for all 21 000 workgroups of a batch serialises them on one address)
     const uint32_t chunk = blockIdx.x / blocks_per_chunk;
+    // (the launch's last chunk may be a prefix: fewer trials, fewer workgroups in its line)
+    const uint32_t trials = chunk + 1 == a.n_chunks ? trials_last : trials_full;
+    const uint32_t my_blocks = (trials + kSlabBlock - 1) / kSlabBlock;
+    if (blockIdx.x % blocks_per_chunk >= my_blocks)
+        return;
     if (tid == 0)
         s_ticket = atomicAdd(reinterpret_cast<unsigned int *>(lb + static_cast<uint64_t>(a.n_chunks) * blocks_per_chunk + chunk), 1u);
     __syncthreads();
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(kSlabThreads) void polar_slab_kernel(NormalsArgs a,
             __hip_atomic_store(mine + blk, kLbPrefix | (excl + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_base = static_cast<uint32_t>(excl);
             s_count = run;
-            if (blk + 1 == blocks_per_chunk)
+            if (blk + 1 == my_blocks)
                 a.counts[chunk] = static_cast<uint32_t>(excl + run);
         }
     }
@@ -391,49 +410,53 @@ __global__ __launch_bounds__(256) void normals_finish_kernel(const uint32_t *cou
 } // namespace
 
 int launch_mt_generate(const uint64_t *ring, uint32_t ring_rows, uint32_t first_row, uint64_t *out, uint32_t n_chunks,
-                       uint32_t chunk_words, int pack, void *stream)
+                       uint32_t chunk_words, uint32_t last_words, int pack, void *stream)
 {
     if (n_chunks == 0)
         return hipSuccess;
-    if (chunk_words % kMtN != 0 || first_row >= ring_rows || n_chunks > ring_rows)
+    if (chunk_words % kMtN != 0 || last_words % kMtN != 0 || last_words > chunk_words || first_row >= ring_rows || n_chunks > ring_rows)
         return hipErrorInvalidValue;
     if (pack >= 4)
         hipLaunchKernelGGL(mt_generate_kernel<4>, dim3((n_chunks + 3) / 4), dim3(kGenThreads * 4), 0, static_cast<hipStream_t>(stream),
-                           ring, ring_rows, first_row, out, chunk_words, n_chunks);
+                           ring, ring_rows, first_row, out, chunk_words, last_words, n_chunks);
     else
         hipLaunchKernelGGL(mt_generate_kernel<1>, dim3(n_chunks), dim3(kGenThreads), 0, static_cast<hipStream_t>(stream), ring,
-                           ring_rows, first_row, out, chunk_words, n_chunks);
+                           ring_rows, first_row, out, chunk_words, last_words, n_chunks);
     return hipGetLastError();
 }
 
 int launch_mt_jump(uint64_t *ring, uint32_t ring_rows, uint32_t src_first, uint32_t dst_first, const uint64_t *poly,
-                   uint32_t n_tasks, void *stream)
+                   uint32_t n_tasks, int pack, void *stream)
 {
     if (n_tasks == 0)
         return hipSuccess;
     if (src_first >= ring_rows || dst_first >= ring_rows || n_tasks > ring_rows)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mt_jump_kernel, dim3(n_tasks), dim3(kJumpThreads), 0, static_cast<hipStream_t>(stream), ring, ring_rows,
-                       src_first, dst_first, poly);
+    if (pack >= 3)
+        hipLaunchKernelGGL(mt_jump_kernel<3>, dim3((n_tasks + 2) / 3), dim3(kJumpThreads * 3), 0, static_cast<hipStream_t>(stream), ring,
+                           ring_rows, src_first, dst_first, poly, n_tasks);
+    else
+        hipLaunchKernelGGL(mt_jump_kernel<1>, dim3(n_tasks), dim3(kJumpThreads), 0, static_cast<hipStream_t>(stream), ring, ring_rows,
+                           src_first, dst_first, poly, n_tasks);
     return hipGetLastError();
 }
 
 int launch_mt_normals(const NormalsArgs &a, void *stream)
 {
-    if (a.n_chunks == 0 || a.blocks == 0)
+    if (a.n_chunks == 0 || a.blocks == 0 || a.last_blocks == 0)
         return hipSuccess;
     const uint32_t trials = kBlockTrials * a.blocks;
-    if (a.first_row >= a.ring_rows || a.n_chunks > a.ring_rows || a.slab_words < 2ull * trials || !a.raw || !a.lookback)
+    if (a.first_row >= a.ring_rows || a.n_chunks > a.ring_rows || a.last_blocks > a.blocks || a.slab_words < 2ull * trials || !a.raw || !a.lookback)
         return hipErrorInvalidValue;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int rc = launch_mt_generate(a.ring, a.ring_rows, a.first_row, a.raw, a.n_chunks, kMtN * a.blocks, a.pack, stream);
+    int rc = launch_mt_generate(a.ring, a.ring_rows, a.first_row, a.raw, a.n_chunks, kMtN * a.blocks, kMtN * a.last_blocks, a.pack, stream);
     if (rc != hipSuccess)
         return rc;
     const uint32_t bpc = (trials + kSlabBlock - 1) / kSlabBlock;
     rc = hipMemsetAsync(a.lookback, 0, 8 * normals_lookback_words(a.n_chunks, a.blocks), s);
     if (rc != hipSuccess)
         return rc;
-    hipLaunchKernelGGL(polar_slab_kernel, dim3(a.n_chunks * bpc), dim3(kSlabThreads), 0, s, a, trials, bpc);
+    hipLaunchKernelGGL(polar_slab_kernel, dim3(a.n_chunks * bpc), dim3(kSlabThreads), 0, s, a, trials, kBlockTrials * a.last_blocks, bpc);
     return hipGetLastError();
 }
 

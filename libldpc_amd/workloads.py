@@ -23,7 +23,12 @@ WORKLOADS = {
               channel="AWGN", x=-4.0, decoding="BP", iterations=50, early_term=True, batch=65536),
     # configs[1] through the opt-in NON-PARITY fast mode (binary32 messages): never the headline
     "2f": dict(name=f"{_H} AWGN -4 dB BP 50 iters early-term batch=65536/GPU seed 0, NON-PARITY fast mode (binary32 messages)",
-               code="h", channel="AWGN", x=-4.0, decoding="BP", iterations=50, early_term=True, batch=65536, fast=True),
+               code="h", channel="AWGN", x=-4.0, decoding="BP", iterations=50, early_term=True, batch=65536, fast=1),
+    # configs[1] through the opt-in NON-PARITY layered schedule (one wavefront per frame), binary32 / binary16 messages
+    "2l": dict(name=f"{_H} AWGN -4 dB BP 50 iters early-term batch=65536/GPU seed 0, NON-PARITY layered schedule (binary32 messages)",
+               code="h", channel="AWGN", x=-4.0, decoding="BP", iterations=50, early_term=True, batch=65536, fast=2),
+    "2h": dict(name=f"{_H} AWGN -4 dB BP 50 iters early-term batch=65536/GPU seed 0, NON-PARITY layered schedule (binary16 messages)",
+               code="h", channel="AWGN", x=-4.0, decoding="BP", iterations=50, early_term=True, batch=65536, fast=3),
     "2n": dict(name=f"{_H} AWGN -4 dB BP 50 iters --no-early-term batch=65536/GPU seed 0", code="h", channel="AWGN",
                x=-4.0, decoding="BP", iterations=50, early_term=False, batch=65536),
     # configs[2]

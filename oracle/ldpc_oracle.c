@@ -719,6 +719,8 @@ static int dec_decode_ratio(dec_t *d)
         for (int p = H->cptr[i]; p < H->cptr[i + 1]; ++p)
             d->v2c[H->cedge[p]] = v0;
     }
+    /* shared-reciprocal check nodes (detmath.h): with early termination, for codes the LDS-resident decoder takes */
+    const int shared = d->early_term && handover_applies(d->code);
     unsigned I = 0;
     int ret = -1;
     for (;;)
@@ -732,7 +734,7 @@ static int dec_decode_ratio(dec_t *d)
                 escaped = 1;
                 break;
             }
-            escaped |= cn_update_ratio(d, H->redge + H->rptr[i], cw, d->early_term);
+            escaped |= cn_update_ratio(d, H->redge + H->rptr[i], cw, shared);
         }
         if (escaped)
             break;

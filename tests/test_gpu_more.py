@@ -426,3 +426,36 @@ def test_fast_mode_is_opt_in_and_close(dec):
     d.stream_begin("AWGN", 0, -4.5)
     b = d.stream_decode(2000, decoding="BP_MS")
     assert np.array_equal(a["iters"], b["iters"]) and np.array_equal(a["bit_errors"], b["bit_errors"])
+
+
+@pytest.mark.parametrize("mode,name", [(2, "binary32 messages"), (3, "binary16 messages")])
+def test_layered_modes_are_opt_in_and_decode(mode, name):
+    """SURVEY §8f item 4, the layered (row-serial) schedule of kernels_layered.hip: NON-PARITY, opt-in.  Over 131 072
+    frames of the headline stream the frame-error rate stays within a factor of the flooding binary64 path's (the
+    schedule and the clipping differ: this is a bound on "still a decoder", the measured deltas are in profiles/), the
+    decisions of frames both declare correct are valid codewords, a converged frame's syndrome is zero, and a sweep
+    count clearly below the flooding iteration count is what the schedule is for."""
+    import libldpc_amd
+    code = orc.Code(orc.H_TXT)
+    d = libldpc_amd.HipDecoder(orc.H_TXT)
+    n = 131072
+    d.stream_begin("AWGN", 0, -4.0)
+    ref = d.stream_decode(n)
+    d.set_fast_mode(mode)
+    d.stream_begin("AWGN", 0, -4.0)
+    lay = d.stream_decode(n, want=("iters", "bit_errors"))
+    d.stream_begin("AWGN", 0, -4.0)
+    few = d.stream_decode(64, want=("iters", "bit_errors", "hard", "llr_out", "llr_in"))
+    d.set_fast_mode(0)
+    d.stream_begin("AWGN", 0, -4.0)
+    again = d.stream_decode(1000, want=("iters", "llr_in"))
+    assert np.array_equal(again["iters"], ref["iters"][:1000])  # switching it off restores the parity path
+    assert np.array_equal(few["llr_in"][:8], again["llr_in"][:8])  # the channel is the binary64 one in every mode
+    fer_ref, fer_lay = (ref["bit_errors"] > 0).mean(), (lay["bit_errors"] > 0).mean()
+    assert fer_ref > 5e-4 and fer_lay < 2.5 * fer_ref + 1e-4, (name, fer_ref, fer_lay)
+    assert 3 < lay["iters"].mean() < 0.75 * ref["iters"].mean(), (name, lay["iters"].mean(), ref["iters"].mean())
+    for f in range(64):
+        if few["iters"][f] < 50:  # converged: the decisions satisfy every check and the LLR signs agree with them
+            assert not code.syndrome(few["hard"][f]).any(), (name, f)
+            assert np.array_equal(few["hard"][f], (few["llr_out"][f] <= 0).astype(np.uint8)), (name, f)
+    assert (few["bit_errors"][few["iters"] < 50] == 0).all()

@@ -23,7 +23,7 @@ B = args.batch or w["batch"]
 d = HipDecoder(workloads.code_path(w))
 d.set_profiling(True)
 d.set_bec_compat(w.get("bec_compat", False))
-d.set_fast_mode(w.get("fast", False))
+d.set_fast_mode(int(w.get("fast", 0)))
 d.stream_begin(w["channel"], 0, w["x"])
 it = np.zeros(B, np.uint32); be = np.zeros(B, np.uint32)
 kw = dict(early_term=w["early_term"], iterations=w["iterations"], decoding=w["decoding"], want=(), out={"iters": it, "bit_errors": be})

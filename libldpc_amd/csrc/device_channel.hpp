@@ -49,22 +49,43 @@ __device__ __forceinline__ void channel_init(const DecodeArgs &a, uint64_t frame
             // of the frame's first pair — a first guess from the expected pairs per slab, corrected on the table of
             // cumulative counts (wave-uniform: scalar loads); a frame's pairs then lie in that slab or the ones after it.
             const auto cum = uniform_table(a.slab_cum);
-            const uint64_t rel_lo = q_lo - a.pair_origin;
+            const uint64_t rel_lo = q_lo - a.pair_origin, rel_hi = q_hi - a.pair_origin;
             uint32_t j0 = static_cast<uint32_t>(static_cast<float>(rel_lo) * a.slab_pairs_inv);
             j0 = j0 < a.n_slabs ? j0 : a.n_slabs - 1;
-            while (j0 > 0 && rel_lo < cum[j0])
-                --j0;
-            while (j0 + 1 < a.n_slabs && rel_lo >= cum[j0 + 1])
-                ++j0;
+            // four consecutive table entries around the guess, fetched together (the table is followed by four entries of
+            // 2^64-1): ONE round trip to memory covers the guess being off by one slab either way — a decode workgroup that
+            // owns its CU (the n=8192 code) has no other frame to hide a chain of dependent loads behind
+            const uint32_t jb = j0 > 0 ? j0 - 1 : 0;
+            const uint64_t c0 = cum[jb], c1 = cum[jb + 1], c2 = cum[jb + 2], c3 = cum[jb + 3];
+            const bool window = c0 <= rel_lo && rel_hi < c3;
+            if (!window) // (a guess off by more than one slab: walk the table)
+            {
+                while (j0 > 0 && rel_lo < cum[j0])
+                    --j0;
+                while (j0 + 1 < a.n_slabs && rel_lo >= cum[j0 + 1])
+                    ++j0;
+            }
             for (uint64_t q = q_lo + tid; q <= q_hi; q += kThreads)
             {
                 const uint64_t rel = q - a.pair_origin;
-                uint32_t j = j0;
-                while (j + 1 < a.n_slabs && rel >= a.slab_cum[j + 1])
-                    ++j;
+                uint32_t j;
+                uint64_t base;
+                if (window)
+                {
+                    const uint32_t k = (rel >= c1) + (rel >= c2);
+                    j = jb + k;
+                    base = k == 0 ? c0 : (k == 1 ? c1 : c2);
+                }
+                else
+                {
+                    j = j0;
+                    while (j + 1 < a.n_slabs && rel >= a.slab_cum[j + 1])
+                        ++j;
+                    base = a.slab_cum[j];
+                }
                 // streamed once: non-temporal, so that the 8 KB of a frame do not push the slot tables — which every
                 // frame that starts on this CU reads — out of the CU's 32 KB vector cache
-                const uint64_t *pq = a.pairs + static_cast<uint64_t>(j) * a.slab_words + 2 * (rel - a.slab_cum[j]);
+                const uint64_t *pq = a.pairs + static_cast<uint64_t>(j) * a.slab_words + 2 * (rel - base);
                 ulonglong2 pp;
                 pp.x = __builtin_nontemporal_load(pq), pp.y = __builtin_nontemporal_load(pq + 1);
                 const double nrm[2] = {dm_from_bits(pp.x), dm_from_bits(pp.y)};

@@ -942,7 +942,7 @@ Engine::NoisePass Engine::noise_pass(uint64_t chunk, uint32_t full, uint32_t las
     // (two slabs of slack: the number of chunks a batch spans varies by one, and growing a buffer means freeing it first)
     np.slabs = write_normals ? static_cast<uint64_t *>(slabs_[buf].reserve(8 * slab_words * (np.n_slabs + 2))) : nullptr;
     // (a counting pass must not touch the slab table a decode launch in flight may still read)
-    np.cum = static_cast<uint64_t *>((write_normals ? slab_cum_[buf] : nz_cum_skip_).reserve(8 * (static_cast<size_t>(np.n_slabs) + 1)));
+    np.cum = static_cast<uint64_t *>((write_normals ? slab_cum_[buf] : nz_cum_skip_).reserve(8 * (static_cast<size_t>(np.n_slabs) + 8)));
     uint32_t *counts = static_cast<uint32_t *>(nz_counts_.reserve(4 * static_cast<size_t>(np.n_slabs)));
     NormalsResult *res = static_cast<NormalsResult *>(nz_result_.reserve(sizeof(NormalsResult)));
     na.slabs = np.slabs;

@@ -50,7 +50,8 @@ struct DecodeArgs
     const double *llr_in; // [n_frames][nc], column order
     // kModeAwgn: the two normals (bit patterns of y*mult, x*mult) of every accepted polar pair of the stream, as the noise
     // generator left them: one SLAB per generator chunk, compacted inside the slab in stream order (rng_kernels.hip,
-    // mt_normals_kernel).  slab_cum[j] = pairs in the slabs before j (slab_cum[0] = 0, n_slabs + 1 entries); the pair with
+    // polar_slab_kernel).  slab_cum[j] = pairs in the slabs before j (slab_cum[0] = 0, n_slabs + 1 entries, followed by four
+    // entries of 2^64-1); the pair with
     // stream index q sits in the slab j with slab_cum[j] <= q - pair_origin < slab_cum[j+1], at
     // pairs[j * slab_words + 2 * (q - pair_origin - slab_cum[j])].  Normal g = frame*nct + i comes from pair g>>1.
     const uint64_t *pairs;

@@ -378,6 +378,8 @@ __global__ __launch_bounds__(256) void normals_finish_kernel(const uint32_t *cou
     }
     uint64_t runsum = tid ? part[tid - 1] : 0;
     const uint64_t total = part[255];
+    if (tid < 4)
+        cum[n + 1 + tid] = ~0ull; // (the decode kernels read four consecutive entries around a slab: no slab beyond the last)
     if (tid == 0)
     {
         cum[n] = total;

@@ -69,53 +69,68 @@ __device__ __forceinline__ uint32_t ring_index(uint32_t rows, uint32_t first, ui
     return r >= rows ? r - rows : r;
 }
 
+// 32-bit data-parallel-primitive move on a 64-bit value (two halves): lane i receives lane i+1 (lane 63: 0)
+__device__ __forceinline__ uint64_t dpp_wave_up1(uint64_t x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(x >> 32), 0x130, 0xF, 0xF, true);
+    return (static_cast<uint64_t>(static_cast<uint32_t>(hi)) << 32) | static_cast<uint32_t>(lo);
+}
+
+// Thread t < 156 of a chunk's three waves holds the sequence words L = x[312 b + t] and H = x[312 b + 156 + t] of the
+// current block b IN REGISTERS.  The twist
+//     x[k + 312] = x[k + 156] ^ f(x[k], x[k + 1])
+// needs the right-hand neighbour's pair (L, H): one whole-wave lane shift, plus four edge values per block that cross the
+// waves through LDS (wave 1 lane 0, wave 2 lane 0, and wave 0 lanes 0 and 1 for thread 155, whose neighbour "156" is
+// (H_0, new L_0)), double-buffered by the block's parity: ONE workgroup barrier per block where the LDS-resident state of
+// rounds 1-2 needed three.  The serial chain per chunk is what the side stream's duration is made of.
 template <int kGenChunks>
 __global__ __launch_bounds__(kGenThreads *kGenChunks) void mt_generate_kernel(const uint64_t *ring, uint32_t ring_rows, uint32_t first_row,
                                                                               uint64_t *out, uint32_t chunk_words, uint32_t last_words,
                                                                               uint32_t n_chunks)
 {
-    __shared__ uint64_t xs[kGenChunks][kMtN];
+    __shared__ uint64_t edge[kGenChunks][2][4][2]; // [chunk of the workgroup][parity][w0 l0, w0 l1, w1 l0, w2 l0][L, H]
     const int t = threadIdx.x % kGenThreads, sub = threadIdx.x / kGenThreads;
+    const int lane = t & 63, w = t >> 6;
     const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kGenChunks + sub;
     const bool live = c < n_chunks; // (the last workgroup may hold fewer chunks; its idle waves still meet the barriers)
-    uint64_t *x = xs[sub];
-    if (live)
+    uint64_t L = 0, H = 0;
+    if (live && t < 156)
     {
         const uint64_t *s = ring + static_cast<size_t>(ring_index(ring_rows, first_row, static_cast<uint32_t>(c))) * kMtN;
-        for (int k = t; k < kMtN; k += kGenThreads)
-            x[k] = s[k];
+        L = s[t], H = s[t + 156];
     }
-    __syncthreads();
     uint64_t *o = out + c * chunk_words;
     const uint32_t blocks = chunk_words / kMtN;
     // the launch's last chunk may be a prefix (last_words <= chunk_words): its waves keep meeting the barriers
     const uint32_t my_blocks = c + 1 == n_chunks ? last_words / kMtN : blocks;
+    const int my_slot = w == 0 ? lane : w + 1; // where lanes 0 (and lane 1 of wave 0) publish
+    const bool publisher = lane == 0 || (w == 0 && lane == 1);
+    if (publisher)
+        edge[sub][0][my_slot][0] = L, edge[sub][0][my_slot][1] = H;
+    __syncthreads();
     for (uint32_t b = 0; b < blocks; ++b)
     {
-        uint64_t lo = 0, hi = 0, lo1 = 0, hi1 = 0;
-        const bool act = live && t < 156 && b < my_blocks;
-        if (act)
+        const int par = b & 1;
+        if (live && t < 156 && b < my_blocks)
         {
-            lo = x[t], hi = x[t + 156];
-            lo1 = x[t + 1];                           // t+1 <= 156
-            hi1 = t + 157 < kMtN ? x[t + 157] : 0;    // word 312 wraps to the NEW word 0, taken below
-            o[b * kMtN + t] = mt_temper(lo);
-            o[b * kMtN + 156 + t] = mt_temper(hi);
+            o[b * kMtN + t] = mt_temper(L);
+            o[b * kMtN + 156 + t] = mt_temper(H);
         }
-        __syncthreads();
-        uint64_t nlo = 0;
-        if (act)
+        uint64_t L1 = dpp_wave_up1(L), H1 = dpp_wave_up1(H);
+        if (lane == 63 && w < 2) // thread 64 (w + 1) sits in the next wave
+            L1 = edge[sub][par][w + 2][0], H1 = edge[sub][par][w + 2][1];
+        if (t == 155) // x[156] = H_0 and x[312] = the NEW word 0, formed here from L_0, L_1, H_0
         {
-            nlo = mt_twist(lo, lo1, hi); // x[k+156] of the current window
-            x[t] = nlo;
+            const uint64_t l0 = edge[sub][par][0][0], h0 = edge[sub][par][0][1], l1 = edge[sub][par][1][0];
+            L1 = h0;
+            H1 = mt_twist(l0, l1, h0);
         }
-        __syncthreads();
-        if (act)
-        {
-            if (t == 155)
-                hi1 = x[0]; // new word 0
-            x[t + 156] = mt_twist(hi, hi1, nlo); // (k+156) mod 312 = k-156: the new low half
-        }
+        const uint64_t nL = mt_twist(L, L1, H);
+        const uint64_t nH = mt_twist(H, H1, nL);
+        L = nL, H = nH;
+        if (publisher)
+            edge[sub][par ^ 1][my_slot][0] = L, edge[sub][par ^ 1][my_slot][1] = H;
         __syncthreads();
     }
 }

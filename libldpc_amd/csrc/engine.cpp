@@ -674,6 +674,22 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         a.redo_count_in = redo, a.redo_list_in = redo + 1;
         if (handover)
             a.redo_iter_in = redo + 1 + n;
+        else if (plan_.lds_ok)
+        {
+            // The first launch ran the shared-reciprocal check nodes (detmath.h), whose denominator products leave their
+            // range in a few frames per ten thousand at the waterfall (strongly converged frames): those are decoded again
+            // from scratch with every output divided separately — the ratio form still, a twentieth of a millisecond for a
+            // few dozen frames — and only what leaves the box there goes on to the LLR domain.  (A lone frame takes 0.3 ms
+            // in the LLR domain, and the launches of a batch run one after the other.)
+            uint32_t *redo2 = static_cast<uint32_t *>(redo2_.reserve(4 * (n + 1)));
+            check(hipMemsetAsync(redo2, 0, 4, s), "redo count");
+            a.redo_count = redo2, a.redo_list = redo2 + 1;
+            a.ratio_separate = 1;
+            launch();
+            a.ratio_separate = 0;
+            a.redo_count = nullptr, a.redo_list = nullptr;
+            a.redo_count_in = redo2, a.redo_list_in = redo2 + 1;
+        }
     }
     launch();
     a.redo_count_in = nullptr, a.redo_list_in = nullptr, a.redo_iter_in = nullptr, a.ws_handover = nullptr;

@@ -266,7 +266,7 @@ class Engine
     DeviceBuffer enc_snap_;
     uint64_t enc_snap_pos_ = 0;
     bool enc_snap_valid_ = false;
-    DeviceBuffer redo_; // [0] = count, [1..] = frames handed back by the ratio-form launch
+    DeviceBuffer redo_, redo2_; // [0] = count, [1..] = frames handed back by the (first / second) ratio-form launch
     bool profiling_ = false;
     double host_ms_[2] = {0, 0}; // [0] exchange, [1] noise-stream wait
     uint64_t host_n_[2] = {0, 0};

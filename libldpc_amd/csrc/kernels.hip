@@ -803,7 +803,9 @@ constexpr int kMaxVnBlocksInRegs = 8;
 // box is handed to the LLR-domain instantiation at an iteration boundary, its messages converted by one logarithm each
 // (detmath.h "Hand-over"): it is appended to a.redo_list with the iteration to resume at (a.redo_iter) and its c2v
 // messages go to a.ws_handover.  The LLR-domain instantiation resumes such frames (a.redo_iter_in / a.ws_handover).
-template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO, bool HANDOVER = false>
+// SEPARATE (RATIO, LDS-resident, early termination): the frames that escaped from the shared-reciprocal form are decoded
+// again from scratch with every check-node output divided separately (second of three launches, detmath.h).
+template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO, bool HANDOVER = false, bool SEPARATE = false>
 __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 {
     static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
@@ -1017,7 +1019,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             uint32_t bad = 0;
             // LDS-resident decoder with early termination: shared-reciprocal check nodes (detmath.h; the oracle applies the
             // same rule, a property of the code)
-            constexpr bool SH = LDS_RESIDENT && !HANDOVER;
+            constexpr bool SH = LDS_RESIDENT && !HANDOVER && !SEPARATE;
             // blocks two at a time where they match (plan.cpp deals each wave's blocks in degree order); both
             // descriptors arrive with one scalar load (plan.cpp, cn_work_desc)
             for (int w = 0; w < P.cn_work_stride; w += 2)
@@ -1363,10 +1365,10 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 #endif
 }
 
-template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO>
+template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO, bool SEPARATE = false>
 __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 {
-    decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO>(a);
+    decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO, false, SEPARATE>(a);
 }
 
 #ifndef LDPC_AMD_HANDOVER_WAVES
@@ -1763,7 +1765,10 @@ int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *s
     const bool ratio = a.redo_list != nullptr;
     // without early termination the ratio form runs with the hand-over to the LLR-domain form (detmath.h "Hand-over")
     const bool handover = ratio && !a.early_term;
-    if (ratio && (min_sum || a.iterations == 0 || !a.redo_count || a.redo_count_in || (handover && (!a.redo_iter || !a.ws_handover))))
+    if (ratio && (min_sum || a.iterations == 0 || !a.redo_count || (a.redo_count_in && !a.ratio_separate) ||
+                  (handover && (!a.redo_iter || !a.ws_handover))))
+        return hipErrorInvalidValue;
+    if (a.ratio_separate && (!ratio || handover || !LDS_RESIDENT))
         return hipErrorInvalidValue;
     if (a.redo_iter_in && !a.ws_handover)
         return hipErrorInvalidValue;
@@ -1790,8 +1795,12 @@ int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *s
                 k = decode_kernel_w5<false, false, LDS_RESIDENT, MAXD, LLR_MODE, true>;
         }
     if constexpr (LDS_RESIDENT)
+    {
         if (handover)
             k = want_llr ? decode_kernel_handover<true, MAXD, LLR_MODE> : decode_kernel_handover<false, MAXD, LLR_MODE>;
+        else if (ratio && a.ratio_separate)
+            k = want_llr ? decode_kernel<false, true, true, MAXD, LLR_MODE, true, true> : decode_kernel<false, false, true, MAXD, LLR_MODE, true, true>;
+    }
     if (handover && !LDS_RESIDENT)
         return hipErrorInvalidValue; // (the memory-resident decoder runs the LLR-domain form when early termination is off)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -86,6 +86,7 @@ struct DecodeArgs
     // redo_count_in set decodes exactly those frames (block b takes frame redo_list_in[b], b < *redo_count_in)
     uint32_t *redo_list;
     uint32_t *redo_count;
+    int ratio_separate; // ratio form with every check-node output divided separately (the middle launch of three, LDS-resident)
     const uint32_t *redo_list_in;
     const uint32_t *redo_count_in;
     // hand-over (sum-product without early termination, detmath.h "Hand-over"): redo_iter[pos] = iteration the frame

@@ -702,7 +702,7 @@ static int handover_applies(const orc_code *c)
 
 /* returns the iteration count, or -1 when a value left the representable box (the caller decodes the frame again in the
    LLR domain).  early_term off: the frame may be handed over to the LLR-domain form mid-way (detmath.h "Hand-over"). */
-static int dec_decode_ratio(dec_t *d)
+static int dec_decode_ratio(dec_t *d, int allow_shared)
 {
     const spm *H = &d->code->H;
     double *lam = malloc(8 * (size_t)(H->cols > 0 ? H->cols : 1));
@@ -720,7 +720,7 @@ static int dec_decode_ratio(dec_t *d)
             d->v2c[H->cedge[p]] = v0;
     }
     /* shared-reciprocal check nodes (detmath.h): with early termination, for codes the LDS-resident decoder takes */
-    const int shared = d->early_term && handover_applies(d->code);
+    const int shared = allow_shared && d->early_term && handover_applies(d->code);
     unsigned I = 0;
     int ret = -1;
     for (;;)
@@ -804,7 +804,7 @@ static int dec_decode_ratio(dec_t *d)
 static int dec_decode_llr(dec_t *d);
 
 /* test introspection: frames the ratio form finished / handed back since the last reset (not thread-safe) */
-static uint64_t g_ratio_done, g_ratio_escaped;
+static uint64_t g_ratio_done, g_ratio_escaped, g_ratio_second;
 void orc_ratio_stats(uint64_t *done, uint64_t *escaped, int reset)
 {
     if (done)
@@ -820,7 +820,14 @@ static int dec_decode(dec_t *d)
 {
     if (d->cn == jacobian_det && d->iterations > 0 && (d->early_term || handover_applies(d->code)))
     {
-        int it = dec_decode_ratio(d);
+        /* three stages, as the kernels' three launches: shared-reciprocal check nodes; if a value (or a denominator product)
+           leaves its range, again from scratch with separately divided outputs; if the box is left there too, the LLR domain */
+        int it = dec_decode_ratio(d, 1);
+        if (it < 0 && d->early_term && handover_applies(d->code))
+        {
+            ++g_ratio_second;
+            it = dec_decode_ratio(d, 0);
+        }
         if (it >= 0)
         {
             ++g_ratio_done;

@@ -8,7 +8,8 @@ writes profiles/<tag>_configs.jsonl      the bench.py line of every BASELINE con
                                          kernel (SQ sets, FETCH_SIZE, WRITE_SIZE) and the ceilings derived from them, the
                                          same arithmetic as bench.py's roofline (so the line can be checked by hand)
        profiles/<tag>_config_stats.csv   per configuration: kernel-trace stats of the probe run (all kernels above 1 %)
-       profiles/<tag>_fast_mode.jsonl    tools/fast_mode_report.py
+       profiles/<tag>_fast_modes.jsonl   tools/fast_mode_report.py
+       profiles/<tag>_shard_cost_cfg{2,4}.jsonl   tools/shard_probe.py
 """
 import csv, glob, json, os, shutil, sys
 
@@ -54,7 +55,7 @@ for d in sorted(glob.glob(os.path.join(src, "cfg*"))):
         continue
     cfg = os.path.basename(d)[3:]
     per = {}
-    for sub in ("sq", "sq2", "fetch", "write"):
+    for sub in ("sq", "sq2", "mix", "fetch", "write"):
         for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
@@ -88,6 +89,15 @@ for d in sorted(glob.glob(os.path.join(src, "cfg*"))):
                 "wave_wait_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in c else None,
                 "hbm_bytes_per_launch": hbm, "hbm_GBs": hbm / t / 1e9, "hbm_frac_of_8TBs": hbm / t / 1e9 / HBM,
                 "edge_updates_per_launch": eu, "kernel_ms": c["ns"] * 1e-6}
+    if "SQ_INSTS_VALU_FMA_F64" in c:  # work-normalised: binary64 operations retired against 78.6 TFLOP/s (bench.py roofline_from)
+        add, mul, fma, trans = (c[k] for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+        flops = 64.0 * (add + mul + 2 * fma + trans)
+        pmc[cfg].update({"fp64_TFLOPs": flops / t / 1e12, "fp64_frac_of_78.6_TFLOPs": flops / t / 1e12 / (N_SIMD * 16 * 2 * CLOCK / 1e12),
+                         "fp64_share_of_valu_instructions": (add + mul + fma + trans) / c["SQ_INSTS_VALU"],
+                         "lane_instructions_per_edge_update": None if not eu else {
+                             "fp64_add": add * 64 / eu, "fp64_mul": mul * 64 / eu, "fp64_fma": fma * 64 / eu, "fp64_reciprocal": trans * 64 / eu,
+                             "int32": c["SQ_INSTS_VALU_INT32"] * 64 / eu, "int64": c["SQ_INSTS_VALU_INT64"] * 64 / eu,
+                             "convert": c["SQ_INSTS_VALU_CVT"] * 64 / eu, "all_valu": c["SQ_INSTS_VALU"] * 64 / eu}})
     for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if float(r["Percentage"]) >= 1.0:
@@ -106,4 +116,7 @@ for cfg, p in pmc.items():
 
 fm = os.path.join(src, "fast_mode_report.jsonl")
 if os.path.exists(fm):
-    shutil.copy(fm, os.path.join(out, f"{tag}_fast_mode.jsonl"))
+    shutil.copy(fm, os.path.join(out, f"{tag}_fast_modes.jsonl"))
+for name in ("shard_cost_cfg2.jsonl", "shard_cost_cfg4.jsonl"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(out, f"{tag}_{name}"))

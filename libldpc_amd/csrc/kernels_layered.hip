@@ -67,9 +67,9 @@ __device__ __forceinline__ void cn_layered(float *tot, M *c2v, const uint32_t (&
 #pragma unroll
     for (int j = 0; j < D; ++j)
     {
-        t[j] = clip(tot[n[j]] - msg_load(c2v + j * 64)); // what the neighbour says without this node's last message
-        v[j] = l_exp2(t[j]);                             // as a likelihood ratio rho = 2^L2
-    }
+        t[j] = tot[n[j]] - msg_load(c2v + j * 64); // what the neighbour says without this node's last message
+        v[j] = l_exp2(clip(t[j]));                 // as a likelihood ratio rho = 2^L2; only what ENTERS the check node is
+    }                                              // clipped: the total keeps everything the other check nodes have said
     float o[D];
     if constexpr (D == 2)
     {

@@ -502,31 +502,34 @@ DM_FN double dm_frac_lambda2(dm_frac f, dm_frac g)
  *
  * Such a node divides three or four times, each time by a different denominator d_k, and a division is the most
  * expensive thing the iteration does (a 16-cycle reciprocal estimate, two Newton steps, the quotient and its correction).
- * Here the node takes ONE correctly rounded reciprocal r = 1 / P of the product P = d_0 d_1 .. d_{D-1} and recovers every
- * 1 / d_k from it with multiplications (Montgomery's simultaneous inversion):
+ * Here a node of degree 3 takes ONE correctly rounded reciprocal r = 1 / P of the product P = d_0 d_1 d_2 and recovers every
+ * 1 / d_k from it with multiplications (Montgomery's simultaneous inversion); a node of degree 4 does the same for its
+ * denominators two by two:
  *
  *     degree 3    p01 = d0 d1,  P = p01 d2,  r = 1/P
  *                 i2 = r p01,   t = r d2,   i0 = t d1,   i1 = t d0                  lambda(c2v_k) = n_k i_k
- *     degree 4    p01 = d0 d1,  p012 = p01 d2,  P = p012 d3,  r = 1/P
- *                 i3 = r p012,  t = r d3,  i2 = t p01,  u = t d2,  i1 = u d0,  i0 = u d1
+ *     degree 4    p01 = d0 d1,  r01 = 1/p01,  i0 = r01 d1,  i1 = r01 d0;   p23 = d2 d3,  r23 = 1/p23,  i2 = r23 d3,  i3 = r23 d2
  *
  * with the numerators n_k and denominators d_k of dm_ratio_lambda (degree 3) and of the fraction form (degree 4: the two
  * partial results F[1], B[2] stay undivided, dm_ratio_lambda_frac) formed exactly as before.  22 instructions and one
- * reciprocal instead of 30 and three (degree 3), 32 and one instead of 44 and four (degree 4).  Every factor is positive
+ * reciprocal instead of 30 and three (degree 3), 36 and two instead of 44 and four (degree 4).  Every factor is positive
  * and every operation is a plain binary64 multiply, so an output carries about three more roundings than a quotient would:
  * a relative error of a few 1e-16 on a ratio, i.e. that much ABSOLUTE error on the message's LLR per iteration.
  *
- * Range.  Inputs lie in [2^-240, 2^240).  Degree 3: d = 1 + ab in [1, 2^481); degree 4: d in [2^-240, 2^723).  P never
- * underflows (>= 2^-960) but may exceed the double range when several inputs are large at once; the node therefore returns
- * the upper word of P and a frame in which any P reached 2^897 is treated like a frame that left the box: decoded again
- * from scratch by the LLR-domain form.  The threshold is chosen so that the check rides on the escape tracking the form has
- * anyway: (upper word of P) >> 2 reaches DM_RATIO_KEY_SPAN exactly when P >= 2^897 — infinities, NaNs and negative values
+ * Range.  Inputs lie in [2^-240, 2^240).  Degree 3: d = 1 + ab in [1, 2^481); degree 4: d in [2^-240, 2^723).  A product
+ * never underflows (>= 2^-480) but may exceed the double range when several inputs are large at once; the node therefore
+ * returns the upper word of its (larger) product and a frame in which one reached 2^897 is treated like a frame that left
+ * the box: decoded again from scratch (separately divided outputs first, then the LLR domain: three launches).  The
+ * threshold is chosen so that the check rides on the escape tracking the form has anyway: (upper word of P) >> 2 reaches DM_RATIO_KEY_SPAN exactly when P >= 2^897 — infinities, NaNs and negative values
  * included, positive doubles order like their bit patterns — so DM_SHARED_TRACK feeds the same running maximum as
  * DM_RATIO_TRACK (one shift and one max per node, no register of its own; a per-node fall-back to separate quotients was
  * measured first and costs the headline kernel its fifth resident frame: 12 bytes of scratch at 96 registers).  For
  * P < 2^897 every intermediate lies within 2^-+1000 and dm_ratio_div(1, P) is the correctly rounded reciprocal on both
- * sides.  The rule depends on the frame's own data only.  How often it fires (h.txt, AWGN): 0.05 % of the frames at -4 dB,
- * 0.7 % at -2 dB, 6 % at 0 dB, half of them at +2 dB — far above the waterfall, where a frame takes two or three iterations.
+ * sides.  The rule depends on the frame's own data only.  How often it fires (h.txt, AWGN, det-mode oracle): in none of
+ * 20 000 frames at -4 and -2 dB, none of 2 000 at 0 dB, 0.15 % at +2 dB, 1.2 % at +4 dB, most frames at +6 dB (where frames
+ * leave the box of the ratio form itself) — far above the waterfall, where a frame takes two or three iterations.  (One
+ * reciprocal for all four denominators of a degree-4 node, 32 instructions, was measured first: 0.25 % of the frames at
+ * -4 dB overflow it, and a frame decoded again costs its whole latency once more, serialised behind the batch: 0.2 ms.)
  * Frames decoded WITHOUT early termination (hand-over form) keep the separately divided outputs: their messages grow until
  * the hand-over and would overflow P first.
  */
@@ -551,17 +554,25 @@ DM_FN uint32_t dm_cn4_shared(double *v)
 {
     const double nF = DM_FMA(v[0], v[1], 1.0), dF = v[0] + v[1]; /* F[1] = nF / dF */
     const double nB = DM_FMA(v[3], v[2], 1.0), dB = v[3] + v[2]; /* B[2] = nB / dB */
+    /* two pairs, a reciprocal each: the product of all four denominators (about the cube of the product of the node's four
+       inputs) leaves the double range in one frame in four hundred at -4 dB — frames that then have to be decoded again —
+       the product of two does so in none of 60 000.  The pairs one after the other (on the device a scheduling fence
+       between them): side by side they cost the headline kernel a register it does not have. */
     const double n0 = DM_FMA(dB, v[1], nB), d0 = DM_FMA(nB, v[1], dB); /* B[1] = B[2] [+] v[1] */
     const double n1 = DM_FMA(dB, v[0], nB), d1 = DM_FMA(nB, v[0], dB); /* F[0] [+] B[2] */
+    const double p01 = d0 * d1;
+    const double r01 = dm_ratio_div(1.0, p01);
+    const double o0 = n0 * (r01 * d1), o1 = n1 * (r01 * d0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const double n2 = DM_FMA(dF, v[3], nF), d2 = DM_FMA(nF, v[3], dF); /* F[1] [+] B[3] */
     const double n3 = DM_FMA(dF, v[2], nF), d3 = DM_FMA(nF, v[2], dF); /* F[2] = F[1] [+] v[2] */
-    const double p01 = d0 * d1, p012 = p01 * d2, P = p012 * d3;
-    const double r = dm_ratio_div(1.0, P);
-    const double i3 = r * p012, t = r * d3;
-    const double i2 = t * p01, u = t * d2;
-    const double i1 = u * d0, i0 = u * d1;
-    v[0] = n0 * i0, v[1] = n1 * i1, v[2] = n2 * i2, v[3] = n3 * i3;
-    return (uint32_t)(dm_bits(P) >> 32);
+    const double p23 = d2 * d3;
+    const double r23 = dm_ratio_div(1.0, p23);
+    v[0] = o0, v[1] = o1, v[2] = n2 * (r23 * d3), v[3] = n3 * (r23 * d2);
+    const uint32_t h01 = (uint32_t)(dm_bits(p01) >> 32), h23 = (uint32_t)(dm_bits(p23) >> 32);
+    return h01 > h23 ? h01 : h23;
 }
 
 /*

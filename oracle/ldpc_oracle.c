@@ -812,8 +812,11 @@ void orc_ratio_stats(uint64_t *done, uint64_t *escaped, int reset)
     if (escaped)
         *escaped = g_ratio_escaped;
     if (reset)
-        g_ratio_done = g_ratio_escaped = 0;
+        g_ratio_done = g_ratio_escaped = g_ratio_second = 0;
 }
+
+/* test introspection: frames whose first (shared-reciprocal) attempt was given up since the last reset of orc_ratio_stats */
+uint64_t orc_ratio_second(void) { return g_ratio_second; }
 
 /* decoder.cpp:11-78 */
 static int dec_decode(dec_t *d)

@@ -232,6 +232,15 @@ void MtDevice::apply(const std::vector<StateOp> &ops, uint64_t *table, void *str
 uint32_t MtDevice::ensure_ring(uint64_t c_lo, uint64_t c_hi, void *stream)
 {
     uint64_t *table = static_cast<uint64_t *>(ring_buf_.reserve(sizeof(uint64_t) * kMtWords * StateRing::kTotalRows));
+    if (!ring_polys_ready_)
+    {
+        // every stride the ring will ever use (the powers of two up to its window), computed and uploaded NOW: a
+        // polynomial squaring takes the host 10 ms, and the ring's window reaches its full width only after two dozen
+        // batches — inside somebody's timed region
+        for (uint32_t w = 1; w <= StateRing::kWindow; w *= 2)
+            (void)device_poly(w, stream);
+        ring_polys_ready_ = true;
+    }
     std::vector<StateOp> ops;
     ring_.ensure(c_lo, c_hi, ops);
     apply(ops, table, stream);

@@ -112,6 +112,7 @@ class MtDevice
     std::vector<std::pair<uint64_t, void *>> polys_; // (stride in chunks, device copy)
     uint64_t jump_tasks_ = 0;
     int jump_pack_ = 1;
+    bool ring_polys_ready_ = false;
 };
 
 // Raw words of one mt19937_64(seed) stream (BSC / BEC draws, info words, ldpc_hip_mt64).

@@ -747,6 +747,75 @@ __device__ __forceinline__ void vn_update_llr2(bool store_hb, double *msg, uint8
     }
 }
 
+// The same updates with the slot indices in registers (kLlrRegs, min-sum: two u16 per word for nodes of degree <= 2, 16 x u16
+// in eight words for the wave's first block): no table load between the barrier and the first message read.  These run
+// the passes whose hard decisions nobody reads (no early termination: all but the last) and store none.
+template <int DV>
+__device__ __forceinline__ void vn_small_llr2(double *msg, uint32_t packed_a, uint32_t packed_b, double L0, double L1, double &out0,
+                                              double &out1)
+{
+    static_assert(DV >= 1 && DV <= 2, "register-held slot indices");
+    asm volatile("" : "+v"(packed_a), "+v"(packed_b)); // unpack here, every iteration
+    const uint32_t s0[2] = {packed_a & 0xFFFFu, packed_a >> 16}, s1[2] = {packed_b & 0xFFFFu, packed_b >> 16};
+    double c0[DV], c1[DV];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        c0[p] = msg[s0[p]], c1[p] = msg[s1[p]];
+    out0 = L0, out1 = L1;
+#pragma unroll
+    for (int p = 0; p < DV; ++p) // sequential sum in column file order
+        out0 += c0[p], out1 += c1[p];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+    {
+        msg[s0[p]] = out0 - c0[p];
+        msg[s1[p]] = out1 - c1[p];
+    }
+}
+
+template <int DV>
+__device__ __forceinline__ double vn_update_llr_regs(double *msg, const uint32_t (&packed)[8], double L)
+{
+    // the words stay packed across iterations (see vn_update_ratio_regs) and are unpacked once for the reads and once
+    // more for the writes: sixteen unpacked addresses kept across the sum are sixteen registers
+    auto unpack = [&](uint32_t (&pk)[(DV + 1) / 2]) {
+#pragma unroll
+        for (int i = 0; i < (DV + 1) / 2; ++i)
+        {
+            pk[i] = packed[i];
+            asm volatile("" : "+v"(pk[i]));
+        }
+    };
+    uint32_t pk[(DV + 1) / 2], pk2[(DV + 1) / 2];
+    unpack(pk);
+    double c[DV];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        c[p] = msg[(p & 1) ? pk[p >> 1] >> 16 : pk[p >> 1] & 0xFFFFu];
+    double out = L;
+#pragma unroll
+    for (int p = 0; p < DV; ++p) // sequential sum in column file order
+        out += c[p];
+    unpack(pk2);
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        msg[(p & 1) ? pk2[p >> 1] >> 16 : pk2[p >> 1] & 0xFFFFu] = out - c[p];
+    return out;
+}
+
+__device__ __forceinline__ double vn_block_llr_regs(double *msg, const uint32_t (&packed)[8], int degree, double L)
+{
+    switch (degree) // wave-uniform, 1..16
+    {
+#define LDPC_VN(D) \
+    case D: return vn_update_llr_regs<D>(msg, packed, L);
+        LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
+        LDPC_VN(9) LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15) LDPC_VN(16)
+#undef LDPC_VN
+    default: return L;
+    }
+}
+
 __device__ __forceinline__ double vn_block_llr(double *msg, uint8_t *hb, const uint32_t *idx, int count, int degree, double L, bool store_hb)
 {
     switch (degree) // wave-uniform
@@ -763,6 +832,74 @@ __device__ __forceinline__ double vn_block_llr(double *msg, uint8_t *hb, const u
         out += msg[idx[p * count]];
     const uint8_t bit = out <= 0;
     for (int p = 0; p < degree; ++p)
+    {
+        const uint32_t sl = idx[p * count];
+        msg[sl] = out - msg[sl];
+        if (store_hb)
+            hb[sl] = bit;
+    }
+    return out;
+}
+
+// the same for the register-budgeted kernels: up to eight edges unrolled, wider nodes eight messages at a time with every
+// message read twice (the sum still runs in column file order)
+template <int N>
+__device__ __forceinline__ void vn_llr_pass1(const double *msg, const uint32_t *idx, int count, int p0, double &out)
+{
+    uint32_t s[N];
+    double c[N];
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+        s[p] = idx[(p0 + p) * count];
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+        c[p] = msg[s[p]];
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+        out += c[p];
+}
+
+template <int N>
+__device__ __forceinline__ void vn_llr_pass2(double *msg, uint8_t *hb, const uint32_t *idx, int count, int p0, double out, bool store_hb)
+{
+    uint32_t s[N];
+    double c[N];
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+        s[p] = idx[(p0 + p) * count];
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+        c[p] = msg[s[p]];
+    const uint8_t bit = out <= 0;
+#pragma unroll
+    for (int p = 0; p < N; ++p)
+    {
+        msg[s[p]] = out - c[p];
+        if (store_hb)
+            hb[s[p]] = bit;
+    }
+}
+
+__device__ __forceinline__ double vn_block_llr_lean(double *msg, uint8_t *hb, const uint32_t *idx, int count, int degree, double L, bool store_hb)
+{
+    switch (degree) // wave-uniform
+    {
+#define LDPC_VN(D) \
+    case D: return vn_update_llr<D>(msg, hb, idx, count, L, store_hb);
+        LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
+#undef LDPC_VN
+    default: break;
+    }
+    double out = L;
+    int p0 = 0;
+    for (; p0 + 8 <= degree; p0 += 8)
+        vn_llr_pass1<8>(msg, idx, count, p0, out);
+    for (int p = p0; p < degree; ++p)
+        out += msg[idx[p * count]];
+    for (p0 = 0; p0 + 8 <= degree; p0 += 8)
+        vn_llr_pass2<8>(msg, hb, idx, count, p0, out, store_hb);
+    const uint8_t bit = out <= 0;
+    for (int p = p0; p < degree; ++p)
     {
         const uint32_t sl = idx[p * count];
         msg[sl] = out - msg[sl];
@@ -805,9 +942,14 @@ constexpr int kMaxVnBlocksInRegs = 8;
 // messages go to a.ws_handover.  The LLR-domain instantiation resumes such frames (a.redo_iter_in / a.ws_handover).
 // SEPARATE (RATIO, LDS-resident, early termination): the frames that escaped from the shared-reciprocal form are decoded
 // again from scratch with every check-node output divided separately (second of three launches, detmath.h).
-template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO, bool HANDOVER = false, bool SEPARATE = false>
+// VNB (kLlrRegs) = VN blocks per wave the instantiation provides registers for: every one of them costs three registers
+// (LLR, packed slot indices) whether the code has that many blocks or not, so the kernels pinned at five waves per SIMD
+// are compiled for the five blocks per wave of an n = 1024 code and codes with more take the general instantiation.
+template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO, bool HANDOVER = false, bool SEPARATE = false,
+          int VNB = kMaxVnBlocksInRegs>
 __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 {
+    static_assert(VNB >= 1 && VNB <= kMaxVnBlocksInRegs, "register-held VN blocks");
     static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
     static_assert(!HANDOVER || RATIO, "the hand-over leaves the ratio form");
     extern __shared__ double lds[];
@@ -897,16 +1039,17 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             }
         __syncthreads();
     }
-    double my_llr[kMaxVnBlocksInRegs];
-    uint32_t my_idx[kMaxVnBlocksInRegs]; // RATIO: slot indices (two u16) of this lane's nodes of degree <= 2
-    uint32_t wide_idx[8];                // RATIO: slot indices (16 x u16) of this lane's node in the wave's first block
+    double my_llr[VNB + 1];   // (one constant entry of padding: the lock-step loops below name block w + 1, which an odd VNB does not have)
+    uint32_t my_idx[VNB + 1]; // RATIO, MINSUM: slot indices (two u16) of this lane's nodes of degree <= 2
+    my_llr[VNB] = 0.0, my_idx[VNB] = 0;
+    uint32_t wide_idx[8];                // RATIO, MINSUM: slot indices (16 x u16) of this lane's node in the wave's first block
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         wide_idx[i] = 0;
     if constexpr (LLR_MODE == kLlrRegs)
     {
 #pragma unroll
-        for (int w = 0; w < kMaxVnBlocksInRegs; ++w)
+        for (int w = 0; w < VNB; ++w)
         {
             my_llr[w] = 0.0;
             my_idx[w] = 0;
@@ -926,6 +1069,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                             my_llr[w] = dm_exp_clamped(0.0 - my_llr[w]);
                             if (b.degree == 1) // a leaf keeps its channel ratio rho_ch instead (vn_leaf_ratio)
                                 my_llr[w] = dm_ratio_div(1.0, my_llr[w]);
+                        }
+                        if constexpr (RATIO || MINSUM) // (min-sum: latency-bound, the index load of every pass was a third of a node's chain)
+                        {
                             const uint32_t *idx = P.vn_slot + b.idx_off + lane; // LDS-resident: every slot < 2^16
                             if (b.degree >= 1 && b.degree <= 2)
                                 my_idx[w] = idx[0] | (idx[(b.degree - 1) * b.count] << 16);
@@ -960,7 +1106,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         if constexpr (LLR_MODE == kLlrRegs)
         {
 #pragma unroll
-            for (int w = 0; w < kMaxVnBlocksInRegs; ++w)
+            for (int w = 0; w < VNB; ++w)
             {
                 if (w >= P.vn_work_stride)
                     break;
@@ -1130,7 +1276,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     return VnBlock{d0, d1, static_cast<uint16_t>(d2 & 0xFFFFu), static_cast<uint16_t>(d2 >> 16)};
                 };
 #pragma unroll
-                for (int w = 0; w < kMaxVnBlocksInRegs; w += 2) // full low-degree blocks two at a time in lock step
+                for (int w = 0; w < VNB; w += 2) // full low-degree blocks two at a time in lock step
                 {                                               // (plan.cpp deals each wave's blocks in degree order)
                     if (w >= P.vn_work_stride)
                         break;
@@ -1226,14 +1372,73 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             auto vn_one = [&](const VnBlock &b, double L) {
                 if (lane >= b.count)
                     return;
-                const double out = vn_block_llr(msg, hb, P.vn_slot + b.idx_off + lane, b.count, b.degree, L, store_hb);
+                double out;
+                if constexpr (MINSUM && LLR_MODE == kLlrRegs) // (the register-budgeted instantiations: eight edges at a time)
+                    out = vn_block_llr_lean(msg, hb, P.vn_slot + b.idx_off + lane, b.count, b.degree, L, store_hb);
+                else
+                    out = vn_block_llr(msg, hb, P.vn_slot + b.idx_off + lane, b.count, b.degree, L, store_hb);
                 if constexpr (WANT_LLR)
                     out_llr[P.rank_col[b.first + lane]] = out;
             };
-            if constexpr (MINSUM && LLR_MODE == kLlrRegs)
+            // (min-sum, kLlrRegs) the passes whose decisions nobody reads — one block: degree 1 or 2 from its register-held
+            // indices, the wave's first block likewise when it has up to 16 edges per node, anything else through the slot table
+            [[maybe_unused]] auto vn_one_regs = [&](const VnBlock &b, int w, double L) {
+                if (lane >= b.count)
+                    return;
+                double out;
+                if (b.degree >= 1 && b.degree <= 2)
+                {
+                    const uint32_t pk[8] = {my_idx[w], 0, 0, 0, 0, 0, 0, 0};
+                    out = b.degree == 1 ? vn_update_llr_regs<1>(msg, pk, L) : vn_update_llr_regs<2>(msg, pk, L);
+                }
+                else if (w == 0 && b.degree >= 3 && b.degree <= 16)
+                    out = vn_block_llr_regs(msg, wide_idx, b.degree, L);
+                else
+                    out = vn_block_llr_lean(msg, hb, P.vn_slot + b.idx_off + lane, b.count, b.degree, L, false);
+                if constexpr (WANT_LLR)
+                    out_llr[P.rank_col[b.first + lane]] = out;
+            };
+            if (MINSUM && LLR_MODE == kLlrRegs && !store_hb)
             {
 #pragma unroll
-                for (int w = 0; w < kMaxVnBlocksInRegs; w += 2) // full low-degree blocks two at a time in lock step
+                for (int w = 0; w < VNB; w += 2) // full low-degree blocks two at a time in lock step
+                {
+                    if (w >= P.vn_work_stride)
+                        break;
+                    const VnBlock b0 = vn_desc(w);
+                    if (b0.count == 0)
+                        break;
+                    const VnBlock b1 = vn_desc(w + 1 < P.vn_work_stride ? w + 1 : P.vn_work_stride);
+                    if (b1.count == 0)
+                    {
+                        vn_one_regs(b0, w, my_llr[w]);
+                        break;
+                    }
+                    if (b0.degree == b1.degree && b0.degree >= 1 && b0.degree <= 2 && b0.count == kWaveSize &&
+                        b1.count == kWaveSize)
+                    {
+                        double o0, o1;
+                        if (b0.degree == 1)
+                            vn_small_llr2<1>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], o0, o1);
+                        else
+                            vn_small_llr2<2>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], o0, o1);
+                        if constexpr (WANT_LLR)
+                        {
+                            out_llr[P.rank_col[b0.first + lane]] = o0;
+                            out_llr[P.rank_col[b1.first + lane]] = o1;
+                        }
+                    }
+                    else
+                    {
+                        vn_one_regs(b0, w, my_llr[w]);
+                        vn_one_regs(b1, w + 1, my_llr[w + 1]);
+                    }
+                }
+            }
+            else if constexpr (MINSUM && LLR_MODE == kLlrRegs)
+            {
+#pragma unroll
+                for (int w = 0; w < VNB; w += 2) // the same with the hard decisions stored, indices from the slot table
                 {
                     if (w >= P.vn_work_stride)
                         break;
@@ -1252,9 +1457,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                         const uint32_t *i0 = P.vn_slot + b0.idx_off + lane, *i1 = P.vn_slot + b1.idx_off + lane;
                         double o0, o1;
                         if (b0.degree == 1)
-                            vn_update_llr2<1>(store_hb, msg, hb, i0, i1, my_llr[w], my_llr[w + 1], o0, o1);
+                            vn_update_llr2<1>(true, msg, hb, i0, i1, my_llr[w], my_llr[w + 1], o0, o1);
                         else
-                            vn_update_llr2<2>(store_hb, msg, hb, i0, i1, my_llr[w], my_llr[w + 1], o0, o1);
+                            vn_update_llr2<2>(true, msg, hb, i0, i1, my_llr[w], my_llr[w + 1], o0, o1);
                         if constexpr (WANT_LLR)
                         {
                             out_llr[P.rank_col[b0.first + lane]] = o0;
@@ -1374,19 +1579,20 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 #ifndef LDPC_AMD_HANDOVER_WAVES
 #define LDPC_AMD_HANDOVER_WAVES 5
 #endif
-template <bool WANT_LLR, int MAXD, int LLR_MODE>
+template <bool WANT_LLR, int MAXD, int LLR_MODE, int VNB = kMaxVnBlocksInRegs>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(LDPC_AMD_HANDOVER_WAVES, 5))) void decode_kernel_handover(const DecodeArgs a)
 {
-    decode_body<false, WANT_LLR, true, MAXD, LLR_MODE, true, true>(a);
+    decode_body<false, WANT_LLR, true, MAXD, LLR_MODE, true, true, false, VNB>(a);
 }
 
 // The same body compiled for five waves per SIMD (at most 96 VGPRs): the instantiations that sit at that boundary
 // anyway (narrow LDS-resident codes without the LLR output) are pinned there, so that a change that costs one or two
 // registers spills them instead of silently losing the fifth resident frame of every CU (-8 %).
+constexpr int kW5VnBlocks = 5;
 template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void decode_kernel_w5(const DecodeArgs a)
 {
-    decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO>(a);
+    decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO, false, false, kW5VnBlocks>(a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1759,7 +1965,7 @@ __global__ __launch_bounds__(256) void division_selftest_kernel(uint64_t n, uint
 }
 
 template <bool LDS_RESIDENT, int MAXD, int LLR_MODE>
-int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *stream)
+int launch_decode_impl(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *stream)
 {
     const bool want_llr = a.llr_out != nullptr;
     const bool ratio = a.redo_list != nullptr;
@@ -1786,8 +1992,9 @@ int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *s
         k = want_llr ? decode_kernel<false, true, LDS_RESIDENT, MAXD, LLR_MODE, false>
                      : decode_kernel<false, false, LDS_RESIDENT, MAXD, LLR_MODE, false>;
     }
+    [[maybe_unused]] const bool few_vn_blocks = a.plan.vn_work_stride <= kW5VnBlocks;
     if constexpr (LDS_RESIDENT && MAXD == 4 && LLR_MODE == kLlrRegs)
-        if (!want_llr)
+        if (!want_llr && few_vn_blocks)
         {
             if (min_sum)
                 k = decode_kernel_w5<true, false, LDS_RESIDENT, MAXD, LLR_MODE, false>;
@@ -1797,7 +2004,12 @@ int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *s
     if constexpr (LDS_RESIDENT)
     {
         if (handover)
+        {
             k = want_llr ? decode_kernel_handover<true, MAXD, LLR_MODE> : decode_kernel_handover<false, MAXD, LLR_MODE>;
+            if constexpr (MAXD == 4 && LLR_MODE == kLlrRegs)
+                if (few_vn_blocks)
+                    k = want_llr ? decode_kernel_handover<true, MAXD, LLR_MODE, kW5VnBlocks> : decode_kernel_handover<false, MAXD, LLR_MODE, kW5VnBlocks>;
+        }
         else if (ratio && a.ratio_separate)
             k = want_llr ? decode_kernel<false, true, true, MAXD, LLR_MODE, true, true> : decode_kernel<false, false, true, MAXD, LLR_MODE, true, true>;
     }
@@ -1810,6 +2022,17 @@ int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *s
     hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(a.n_frames)), dim3(kThreads), lds_bytes,
                        static_cast<hipStream_t>(stream), a);
     return hipGetLastError();
+}
+
+template <bool LDS_RESIDENT, int MAXD, int LLR_MODE>
+int launch_decode(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *stream)
+{
+#ifdef LDPC_AMD_HEADLINE_SHAPE_ONLY // register-allocation experiments: one code shape, a fraction of the build time
+    if constexpr (!(LDS_RESIDENT && MAXD == 4 && LLR_MODE == kLlrRegs))
+        return hipErrorInvalidValue;
+    else
+#endif
+        return launch_decode_impl<LDS_RESIDENT, MAXD, LLR_MODE>(a, min_sum, lds_bytes, stream);
 }
 
 } // namespace

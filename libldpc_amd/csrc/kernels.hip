@@ -549,7 +549,9 @@ __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, 
 
 // A node of up to 16 edges whose slot indices the lane keeps in registers (16 x u16 in eight words, kLlrRegs: the
 // first — widest — VN block of every wave): no table load at all, every message read once.
-template <int DV>
+// TWICE: the words are unpacked once for the reads and once more for the writes — two instructions per edge against the
+// sixteen registers the unpacked addresses occupy across the product and the division otherwise (the hand-over kernel).
+template <int DV, bool TWICE = false>
 __device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32_t (&packed)[8], double lam, uint32_t &escaped)
 {
     // the words stay packed across iterations: without the barrier the compiler hoists all 16 unpacked indices out
@@ -578,6 +580,15 @@ __device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32
     }
     const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u;
     const double tot = dm_ratio_div(1.0, prod);
+    if constexpr (TWICE)
+    {
+#pragma unroll
+        for (int i = 0; i < (DV + 1) / 2; ++i)
+        {
+            pk[i] = packed[i];
+            asm volatile("" : "+v"(pk[i]));
+        }
+    }
 #pragma unroll
     for (int p = 0; p < DV; ++p)
     {
@@ -588,13 +599,14 @@ __device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32
     return prod;
 }
 
+template <bool TWICE = false>
 __device__ __forceinline__ double vn_block_ratio_regs(double *msg, const uint32_t (&packed)[8], int degree, double lam,
                                                       uint32_t &escaped)
 {
     switch (degree) // wave-uniform, 1..16
     {
 #define LDPC_VN(D) \
-    case D: return vn_update_ratio_regs<D>(msg, packed, lam, escaped);
+    case D: return vn_update_ratio_regs<D, TWICE>(msg, packed, lam, escaped);
         LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
         LDPC_VN(9) LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15) LDPC_VN(16)
 #undef LDPC_VN
@@ -1006,6 +1018,51 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     if (tid == 0)
         misc[0] = 0;
 
+    // The work list of this wave with the VN block descriptors in place (plan.cpp, vn_work_desc): one scalar load per
+    // block, none dependent on another (block id -> descriptor costs a second, dependent one).
+    const auto my_vdesc = uniform_table(P.vn_work_desc + wave * (P.vn_work_stride + 1) * 4);
+    auto vn_desc = [&](int w) { // count 0 = none (every row ends in one)
+        const uint32_t d0 = my_vdesc[4 * w], d1 = my_vdesc[4 * w + 1], d2 = my_vdesc[4 * w + 2];
+        return VnBlock{d0, d1, static_cast<uint16_t>(d2 & 0xFFFFu), static_cast<uint16_t>(d2 >> 16)};
+    };
+    // (kLlrRegs; RATIO, MINSUM) the slot indices a lane keeps in registers — two u16 per word for its nodes of degree <= 2,
+    // 16 x u16 in eight words for its node in the wave's first block — are a property of the code: their loads go out
+    // BEFORE the channel's, so that the two round trips to memory overlap (they used to follow each other, block by block)
+    uint32_t my_idx[VNB + 1];
+    uint32_t wide_idx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        wide_idx[i] = 0;
+#pragma unroll
+    for (int w = 0; w <= VNB; ++w)
+        my_idx[w] = 0;
+    auto pick_up_indices = [&] {
+#pragma unroll
+        for (int w = 0; w < VNB; ++w)
+            if (w < P.vn_work_stride)
+            {
+                const VnBlock b = vn_desc(w);
+                if (lane < b.count)
+                {
+                    const uint32_t *idx = P.vn_slot + b.idx_off + lane; // LDS-resident: every slot < 2^16
+                    if (b.degree >= 1 && b.degree <= 2)
+                        my_idx[w] = idx[0] | (idx[(b.degree - 1) * b.count] << 16);
+                    else if (w == 0 && b.degree <= 16)
+                    {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            if (q < b.degree)
+                                wide_idx[q >> 1] |= idx[q * b.count] << (16 * (q & 1));
+                    }
+                }
+            }
+    };
+    // (the hand-over instantiation picks them up after the channel: fifteen more live registers across the channel code
+    // and its allocation falls apart, 36 -> 200 bytes of scratch)
+    constexpr bool kIndicesInRegs = LLR_MODE == kLlrRegs && (RATIO || MINSUM);
+    if constexpr (kIndicesInRegs && !HANDOVER)
+        pick_up_indices();
+
     // ---- channel + LLR initialisation (device_channel.hpp) ----
     channel_init<kThreads>(a, frame, llr, tid);
 #ifdef LDPC_AMD_PHASE_TRACE
@@ -1023,7 +1080,6 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             o[P.rank_col[r]] = llr[r];
     }
 
-    const auto my_vn = uniform_table(P.vn_work + wave * P.vn_work_stride);
     uint32_t escaped = 0; // RATIO: running maximum of dm_ratio_key over the frame's checked values (detmath.h)
     [[maybe_unused]] int32_t ho_key = 0; // HANDOVER: running maximum of dm_handover_key over the variable-node totals
     if constexpr (RATIO && LLR_MODE != kLlrRegs)
@@ -1039,64 +1095,37 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             }
         __syncthreads();
     }
-    double my_llr[VNB + 1];   // (one constant entry of padding: the lock-step loops below name block w + 1, which an odd VNB does not have)
-    uint32_t my_idx[VNB + 1]; // RATIO, MINSUM: slot indices (two u16) of this lane's nodes of degree <= 2
-    my_llr[VNB] = 0.0, my_idx[VNB] = 0;
-    uint32_t wide_idx[8];                // RATIO, MINSUM: slot indices (16 x u16) of this lane's node in the wave's first block
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        wide_idx[i] = 0;
+    if constexpr (kIndicesInRegs && HANDOVER)
+        pick_up_indices();
+    double my_llr[VNB + 1]; // (my_llr, my_idx: one constant entry of padding — the lock-step loops below name block w + 1, which an odd VNB does not have)
+    my_llr[VNB] = 0.0;
     if constexpr (LLR_MODE == kLlrRegs)
     {
 #pragma unroll
         for (int w = 0; w < VNB; ++w)
         {
             my_llr[w] = 0.0;
-            my_idx[w] = 0;
             if (w < P.vn_work_stride)
             {
-                const uint32_t bi = my_vn[w];
-                if (bi != 0xFFFF)
+                const VnBlock b = vn_desc(w);
+                if (lane < b.count)
                 {
-                    const VnBlock b = load_block3(P.vn_blocks, bi);
-                    if (lane < b.count)
+                    my_llr[w] = llr[b.first + lane];
+                    if constexpr (RATIO)
                     {
-                        my_llr[w] = llr[b.first + lane];
-                        if constexpr (RATIO)
-                        {
-                            if (!(__builtin_fabs(my_llr[w]) <= DM_RATIO_LLR_LIMIT))
-                                escaped = ~0u;
-                            my_llr[w] = dm_exp_clamped(0.0 - my_llr[w]);
-                            if (b.degree == 1) // a leaf keeps its channel ratio rho_ch instead (vn_leaf_ratio)
-                                my_llr[w] = dm_ratio_div(1.0, my_llr[w]);
-                        }
-                        if constexpr (RATIO || MINSUM) // (min-sum: latency-bound, the index load of every pass was a third of a node's chain)
-                        {
-                            const uint32_t *idx = P.vn_slot + b.idx_off + lane; // LDS-resident: every slot < 2^16
-                            if (b.degree >= 1 && b.degree <= 2)
-                                my_idx[w] = idx[0] | (idx[(b.degree - 1) * b.count] << 16);
-                            else if (w == 0 && b.degree <= 16)
-                            {
-#pragma unroll
-                                for (int q = 0; q < 16; ++q)
-                                    if (q < b.degree)
-                                        wide_idx[q >> 1] |= idx[q * b.count] << (16 * (q & 1));
-                            }
-                        }
+                        if (!(__builtin_fabs(my_llr[w]) <= DM_RATIO_LLR_LIMIT))
+                            escaped = ~0u;
+                        my_llr[w] = dm_exp_clamped(0.0 - my_llr[w]);
+                        if (b.degree == 1) // a leaf keeps its channel ratio rho_ch instead (vn_leaf_ratio)
+                            my_llr[w] = dm_ratio_div(1.0, my_llr[w]);
                     }
                 }
             }
         }
         __syncthreads(); // every lane holds its LLRs: the message array may now be written
     }
-    // The work lists of this wave with the block descriptors in place (plan.cpp, cn_work_desc / vn_work_desc): one
-    // scalar load per block, none dependent on another (block id -> descriptor costs a second, dependent one).
-    const auto my_vdesc = uniform_table(P.vn_work_desc + wave * (P.vn_work_stride + 1) * 4);
+    // (the check-node work list likewise: cn_work_desc)
     const auto my_cdesc = uniform_table(reinterpret_cast<const uint32_t *>(P.cn_work_desc + wave * P.cn_desc_stride));
-    auto vn_desc = [&](int w) { // count 0 = none (every row ends in one)
-        const uint32_t d0 = my_vdesc[4 * w], d1 = my_vdesc[4 * w + 1], d2 = my_vdesc[4 * w + 2];
-        return VnBlock{d0, d1, static_cast<uint16_t>(d2 & 0xFFFFu), static_cast<uint16_t>(d2 >> 16)};
-    };
     auto cn_desc = [&](int w) { // count 0 = none (every row ends in two)
         const uint32_t d0 = my_cdesc[2 * w], d1 = my_cdesc[2 * w + 1];
         return CnBlock{d0, static_cast<uint16_t>(d1 & 0xFFFFu), static_cast<uint16_t>(d1 >> 16)};
@@ -1138,13 +1167,52 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             msg[e] = 0.0 - dm_log(__builtin_fabs(src[e])); // lambda -> LLR: one logarithm per message
     }
     else
-        for_my_vn_blocks([&](const VnBlock &b, double L) {
+    {
+        // RATIO: L is lambda(L_ch) (kLlrRegs, a leaf: already rho(L_ch)), the first v2c is rho(L_ch)
+        auto first_v2c = [&](const VnBlock &b, double L) {
+            return RATIO ? ((LLR_MODE == kLlrRegs && b.degree == 1) ? L : dm_ratio_div(1.0, L)) : L;
+        };
+        auto from_table = [&](const VnBlock &b, double L) {
             const uint32_t *idx = P.vn_slot + b.idx_off + lane;
-            // RATIO: L is lambda(L_ch) (kLlrRegs, a leaf: already rho(L_ch)), the first v2c is rho(L_ch)
-            const double v0 = RATIO ? ((LLR_MODE == kLlrRegs && b.degree == 1) ? L : dm_ratio_div(1.0, L)) : L;
+            const double v0 = first_v2c(b, L);
             for (int p = 0; p < b.degree; ++p)
                 msg[idx[p * b.count]] = v0;
-        });
+        };
+        if constexpr (kIndicesInRegs)
+        {
+            // through the slot indices the lane holds already (a rolled loop over the slot table: up to 16 dependent
+            // round trips to memory in front of the first iteration)
+#pragma unroll
+            for (int w = 0; w < VNB; ++w)
+            {
+                if (w >= P.vn_work_stride)
+                    break;
+                const VnBlock b = vn_desc(w);
+                if (b.count == 0)
+                    break;
+                if (lane >= b.count)
+                    continue;
+                if (b.degree >= 1 && b.degree <= 2)
+                {
+                    const double v0 = first_v2c(b, my_llr[w]);
+                    msg[my_idx[w] & 0xFFFFu] = v0;
+                    msg[my_idx[w] >> 16] = v0; // (degree 1: the same slot again)
+                }
+                else if (w == 0 && b.degree >= 3 && b.degree <= 16)
+                {
+                    const double v0 = first_v2c(b, my_llr[w]);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (q < b.degree)
+                            msg[(wide_idx[q >> 1] >> (16 * (q & 1))) & 0xFFFFu] = v0;
+                }
+                else
+                    from_table(b, my_llr[w]);
+            }
+        }
+        else
+            for_my_vn_blocks(from_table);
+    }
     __syncthreads();
 
     double *out_llr = WANT_LLR ? a.llr_out + frame * nc : nullptr;
@@ -1165,7 +1233,11 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             uint32_t bad = 0;
             // LDS-resident decoder with early termination: shared-reciprocal check nodes (detmath.h; the oracle applies the
             // same rule, a property of the code)
+#ifdef LDPC_AMD_HANDOVER_SHARED // experiment: the shared-reciprocal check nodes in the hand-over kernel as well
+            constexpr bool SH = LDS_RESIDENT && !SEPARATE;
+#else
             constexpr bool SH = LDS_RESIDENT && !HANDOVER && !SEPARATE;
+#endif
             // blocks two at a time where they match (plan.cpp deals each wave's blocks in degree order); both
             // descriptors arrive with one scalar load (plan.cpp, cn_work_desc)
             for (int w = 0; w < P.cn_work_stride; w += 2)
@@ -1264,7 +1336,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     else if (b.degree == 2)
                         prod = vn_small_ratio<2>(msg, sl, lam, escaped);
                     else if (w == 0 && b.degree <= 16)
-                        prod = vn_block_ratio_regs(msg, wide_idx, b.degree, lam, escaped);
+                        prod = vn_block_ratio_regs<HANDOVER>(msg, wide_idx, b.degree, lam, escaped);
                     else
                         prod = vn_block_ratio(msg, P.vn_slot + b.idx_off + lane, b.count, b.degree, lam, escaped);
                     put_llr(b, prod);
@@ -1588,7 +1660,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(LDPC_A
 // The same body compiled for five waves per SIMD (at most 96 VGPRs): the instantiations that sit at that boundary
 // anyway (narrow LDS-resident codes without the LLR output) are pinned there, so that a change that costs one or two
 // registers spills them instead of silently losing the fifth resident frame of every CU (-8 %).
-constexpr int kW5VnBlocks = 5;
+constexpr int kW5VnBlocks = 7;
 template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void decode_kernel_w5(const DecodeArgs a)
 {

@@ -453,6 +453,16 @@ uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per
             for (uint64_t k = c; k < c + chunks_per_request; ++k)
                 if (sym.row[k % StateRing::kRows] != static_cast<int64_t>(k))
                     return ~0ull; // a requested chunk has no valid row
+            if (gap == 0 && i % 3 != 2) // the engine's look-ahead for a reader going front to back: two requests ahead
+            {
+                ops.clear();
+                t.extend_to(c + 3 * chunks_per_request + 2, ops);
+                if (!sym.apply(ops))
+                    return ~0ull;
+                for (uint64_t k = c; k < c + chunks_per_request; ++k) // (never at the expense of the request's own rows)
+                    if (sym.row[k % StateRing::kRows] != static_cast<int64_t>(k))
+                        return ~0ull;
+            }
         }
     }
     catch (const std::exception &e)
@@ -466,7 +476,7 @@ uint64_t ldpc_hip_selftest_chunk_table(uint64_t first_chunk, uint64_t chunks_per
 uint64_t ldpc_hip_selftest_shard_table(int world, int rank, uint32_t piece_chunks, uint64_t steps, uint64_t *launches)
 {
     StridedTable t;
-    SymbolicTable sym(StridedTable::kMaxRows + 2);
+    SymbolicTable sym(StridedTable::kTotalRows);
     std::vector<StateOp> ops;
     const uint32_t n = piece_chunks + 1;
     const uint64_t stride = static_cast<uint64_t>(world) * piece_chunks;
@@ -477,13 +487,25 @@ uint64_t ldpc_hip_selftest_shard_table(int world, int rank, uint32_t piece_chunk
         {
             const uint64_t first = s * stride + static_cast<uint64_t>(rank) * piece_chunks;
             ops.clear();
-            t.position(first, n, stride, ops);
+            const uint32_t base = t.position(first, n, stride, ops);
             const uint64_t t0 = sym.tasks, l0 = sym.launches;
             if (!sym.apply(ops))
                 return ~0ull;
             for (uint32_t i = 0; i < n; ++i)
-                if (sym.row[i] != static_cast<int64_t>(first + i))
+                if (sym.row[base + i] != static_cast<int64_t>(first + i))
                     return ~0ull;
+            // the look-ahead of the engine (the tables of the next two steps) after two steps in three: a step finds its table
+            // ready (no operation of its own) or pays its one launch itself
+            if (s % 3 != 2)
+            {
+                ops.clear();
+                t.look_ahead(ops);
+                if (!sym.apply(ops))
+                    return ~0ull;
+                for (uint32_t i = 0; i < n; ++i) // (the table in use is untouched)
+                    if (sym.row[base + i] != static_cast<int64_t>(first + i))
+                        return ~0ull;
+            }
             if (s > 0)
                 tasks_after_first += sym.tasks - t0, launches_after_first += sym.launches - l0;
         }

@@ -146,7 +146,11 @@ void *DeviceBuffer::reserve(size_t bytes)
         if (ptr_)
             check(hipFree(ptr_), "hipFree");
         ptr_ = nullptr;
-        size_t want = std::max(bytes, size_ + size_ / 2);
+        // an eighth of slack from the first allocation on: the per-batch buffers of the noise stream follow the number of
+        // chunks a batch spans, which varies by one or two in eighty, and growing means hipFree — a wait for everything
+        // the device has in flight, the decode kernel of the batch before included (it cost a 4 ms step 2 ms whenever a
+        // batch set a new maximum: steps 1, 3, 52 and 64 of the headline run)
+        size_t want = std::max(bytes + bytes / 8, size_ + size_ / 2);
         check(hipMalloc(&ptr_, want), "hipMalloc");
         size_ = want;
     }
@@ -169,6 +173,20 @@ MtDevice::MtDevice()
 
 MtDevice::~MtDevice()
 {
+    if (jump_stream_)
+    {
+        (void)hipStreamSynchronize(static_cast<hipStream_t>(jump_stream_));
+        (void)hipStreamDestroy(static_cast<hipStream_t>(jump_stream_));
+    }
+    for (Ahead &a : ahead_)
+        (void)hipEventDestroy(static_cast<hipEvent_t>(a.event));
+    for (void *e : ev_free_)
+        (void)hipEventDestroy(static_cast<hipEvent_t>(e));
+    if (ev_main_)
+        (void)hipEventDestroy(static_cast<hipEvent_t>(ev_main_));
+    for (void *e : ev_strided_)
+        if (e)
+            (void)hipEventDestroy(static_cast<hipEvent_t>(e));
     for (auto &p : polys_)
         if (p.second)
             (void)hipFree(p.second);
@@ -180,6 +198,13 @@ void MtDevice::reset(uint64_t seed)
         return; // chunk states depend on the seed only; keep them
     seed_ = seed;
     seeded_ = true;
+    if (jump_stream_) // look-ahead launches of the old seed: done before the ring is written again
+        check(hipStreamSynchronize(static_cast<hipStream_t>(jump_stream_)), "sync");
+    for (Ahead &a : ahead_)
+        ev_free_.push_back(a.event);
+    ahead_.clear();
+    for (bool &b : strided_pending_)
+        b = false;
     ring_.invalidate();
     strided_.invalidate();
 }
@@ -243,17 +268,133 @@ uint32_t MtDevice::ensure_ring(uint64_t c_lo, uint64_t c_hi, void *stream)
     }
     std::vector<StateOp> ops;
     ring_.ensure(c_lo, c_hi, ops);
+    // Look-ahead launches (prefetch_ring) in flight: the request waits for those that wrote a row it reads; operations
+    // planned here (a seek, an extension the look-ahead did not cover) read and write rows anywhere: they wait for all.
+    drain_ahead(stream, ops.empty() ? c_hi : ~0ull);
     apply(ops, table, stream);
+    if (!ops.empty())
+    {
+        if (!ev_main_)
+        {
+            hipEvent_t e;
+            check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+            ev_main_ = e;
+        }
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_main_), static_cast<hipStream_t>(stream)), "event");
+        main_dirty_ = true;
+    }
     return static_cast<uint32_t>(c_lo % StateRing::kRows);
+}
+
+void MtDevice::drain_ahead(void *stream, uint64_t below)
+{
+    size_t n = 0;
+    while (n < ahead_.size() && ahead_[n].hi_before < below)
+        ++n;
+    if (n == 0)
+        return;
+    // (one stream, in order: the newest of them implies the others)
+    check(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ahead_[n - 1].event), 0), "wait look-ahead");
+    for (size_t i = 0; i < n; ++i)
+        ev_free_.push_back(ahead_[i].event); // (re-recorded only after this wait has been enqueued: safe to reuse)
+    ahead_.erase(ahead_.begin(), ahead_.begin() + static_cast<std::ptrdiff_t>(n));
+}
+
+void MtDevice::prefetch_ring(uint64_t c_hi)
+{
+    if (!ring_.valid() || !ring_polys_ready_ || std::getenv("LDPC_AMD_NO_LOOKAHEAD"))
+        return;
+    const uint64_t hi_before = ring_.hi();
+    std::vector<StateOp> ops;
+    ring_.extend_to(c_hi, ops);
+    if (ops.empty())
+        return;
+    if (!jump_stream_)
+    {
+        hipStream_t js;
+        check(hipStreamCreateWithFlags(&js, hipStreamNonBlocking), "hipStreamCreate");
+        jump_stream_ = js;
+    }
+    hipStream_t js = static_cast<hipStream_t>(jump_stream_);
+    if (main_dirty_) // rows written on the caller's stream (the seek, the first extensions) are sources here
+    {
+        check(hipStreamWaitEvent(js, static_cast<hipEvent_t>(ev_main_), 0), "wait ring");
+        main_dirty_ = false;
+    }
+    apply(ops, ring(), js);
+    void *ev;
+    if (!ev_free_.empty())
+        ev = ev_free_.back(), ev_free_.pop_back();
+    else
+    {
+        hipEvent_t e;
+        check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+        ev = e;
+    }
+    check(hipEventRecord(static_cast<hipEvent_t>(ev), js), "event");
+    ahead_.push_back({hi_before, ring_.hi(), ev});
 }
 
 uint64_t *MtDevice::ensure_strided(uint64_t first, uint32_t n, uint64_t stride, void *stream)
 {
-    uint64_t *table = static_cast<uint64_t *>(strided_buf_.reserve(sizeof(uint64_t) * kMtWords * (StridedTable::kMaxRows + 2)));
+    uint64_t *table = static_cast<uint64_t *>(strided_buf_.reserve(sizeof(uint64_t) * kMtWords * StridedTable::kTotalRows));
     std::vector<StateOp> ops;
-    strided_.position(first, n, stride, ops);
+    const uint32_t base = strided_.position(first, n, stride, ops);
+    // a look-ahead launch wrote the table that is read now; operations planned here may touch any table: they wait for all
+    for (uint32_t k = 0; k < StridedTable::kSlots; ++k)
+        if (strided_pending_[k] && (k == base / StridedTable::kMaxRows || !ops.empty()))
+        {
+            check(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_strided_[k]), 0), "wait look-ahead");
+            strided_pending_[k] = false;
+        }
     apply(ops, table, stream);
-    return table;
+    if (!ops.empty())
+    {
+        if (!ev_main_)
+        {
+            hipEvent_t e;
+            check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+            ev_main_ = e;
+        }
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_main_), static_cast<hipStream_t>(stream)), "event");
+        main_dirty_ = true;
+    }
+    return table + static_cast<size_t>(base) * kMtWords;
+}
+
+void MtDevice::prefetch_strided()
+{
+    if (std::getenv("LDPC_AMD_NO_LOOKAHEAD") || !strided_buf_.get())
+        return;
+    std::vector<StateOp> ops;
+    strided_.look_ahead(ops);
+    if (ops.empty())
+        return;
+    if (!jump_stream_)
+    {
+        hipStream_t js;
+        check(hipStreamCreateWithFlags(&js, hipStreamNonBlocking), "hipStreamCreate");
+        jump_stream_ = js;
+    }
+    hipStream_t js = static_cast<hipStream_t>(jump_stream_);
+    if (main_dirty_)
+    {
+        check(hipStreamWaitEvent(js, static_cast<hipEvent_t>(ev_main_), 0), "wait table");
+        main_dirty_ = false;
+    }
+    for (const StateOp &op : ops) // one launch per table, its event for the step that reads that table
+    {
+        apply({op}, static_cast<uint64_t *>(strided_buf_.get()), js);
+        const uint32_t k = op.dst / StridedTable::kMaxRows;
+        if (!ev_strided_[k])
+        {
+            hipEvent_t e;
+            check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+            ev_strided_[k] = e;
+        }
+        check(hipEventRecord(static_cast<hipEvent_t>(ev_strided_[k]), js), "event");
+        strided_pending_[k] = true;
+    }
 }
 
 const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream, int buffer)
@@ -278,6 +419,12 @@ const uint64_t *MtStream::generate(uint64_t first, uint64_t count, void *stream,
         words = static_cast<uint32_t>(std::min<uint64_t>(need, cw));
     }
     check(launch_mt_generate(st.ring(), MtDevice::ring_rows(), row, raw, n, words, words, n == 1 ? 1 : pack_, s), "mt_generate");
+    // a reader going through the stream front to back (one rank: every request starts where the one before ended): the
+    // chunk start states of the next request but one, now (MtDevice::prefetch_ring).  A rank of a sharded stream reads its
+    // share of every step, a fixed distance apart: nothing to look ahead for, the ring moves by that distance in one launch.
+    if (first == last_end_ && n > 1)
+        st.prefetch_ring(c_hi + 2 * (static_cast<uint64_t>(n) + 1));
+    last_end_ = first + count;
     return raw + (first - c_lo * cw);
 }
 
@@ -1054,6 +1201,9 @@ void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream, bool write_no
     cur_chunk_ += np.res.next_slab;
     cur_k_ = np.res.next_k;
     cur_pair_ = qn;
+    // the chunk start states of the next batch but one, now: their jump-ahead chain then runs beside the next batch's
+    // generator chain (both hide under decode kernels whose waves outrank them, kernels.hip), not in front of it
+    noise_.st.prefetch_ring(cur_chunk_ + 2 * (static_cast<uint64_t>(np.n_slabs) + 2));
 }
 
 // raw 64-bit draws consumed from the noise stream since stream_begin (what orc_chan_raw_draws counts)
@@ -1304,6 +1454,9 @@ Engine::ShardStep Engine::stream_decode_sharded(Comm &comm, const DecParams &p, 
             np = noise_pass(sh_chunk_ + static_cast<uint64_t>(r) * g.m, g.m, g.margin_blocks, g.m, 0, 0, buf, true, true, stride);
             prof_mark(1, s);
             send[0] = np.res.piece, send[1] = np.res.total;
+            // the chunk start states of the next step but one, now: their jump-ahead chain has a whole step to run, on a stream
+            // of its own, and every step's generator chain starts at once (MtDevice::prefetch_strided)
+            noise_.st.prefetch_strided();
         }
         catch (const std::exception &e)
         {

@@ -92,11 +92,18 @@ class MtDevice
     uint64_t chunk_trials() const { return chunk_words() / 2; }
     // consecutive chunks [c_lo, c_hi): their start states in the ring; returns the ring row of c_lo
     uint32_t ensure_ring(uint64_t c_lo, uint64_t c_hi, void *stream);
+    // look-ahead: the start states of the chunks up to c_hi computed NOW, on a stream of this object's own, so that the
+    // jump-ahead chain of a later request runs beside the generator chain of an earlier one instead of in front of it
+    // (ensure_ring waits for exactly the look-ahead launches whose rows it reads)
+    void prefetch_ring(uint64_t c_hi);
     uint64_t *ring() const { return static_cast<uint64_t *>(ring_buf_.get()); }
     static constexpr uint32_t ring_rows() { return StateRing::kRows; }
     // sharded stream: rows 0 .. n-1 = chunks [first, first + n), consecutive calls `stride` chunks apart cost one launch
     uint64_t *ensure_strided(uint64_t first, uint32_t n, uint64_t stride, void *stream);
-    static constexpr uint32_t strided_rows() { return StridedTable::kMaxRows + 2; }
+    static constexpr uint32_t strided_rows() { return StridedTable::kMaxRows; }
+    // look-ahead: the launches that bring the sharded stream's tables of the next two steps into being, now, on the
+    // object's own stream (three tables: the generator of this step reads one while the others are written)
+    void prefetch_strided();
     uint64_t jump_tasks() const { return jump_tasks_; } // jump-ahead tasks launched so far (tools/shard_probe.py)
     void set_jump_pack(int tasks_per_workgroup) { jump_pack_ = tasks_per_workgroup; } // kernels.hpp launch_mt_jump
 
@@ -113,13 +120,27 @@ class MtDevice
     uint64_t jump_tasks_ = 0;
     int jump_pack_ = 1;
     bool ring_polys_ready_ = false;
+    // look-ahead launches in flight on jump_stream_: the ring rows of chunks [hi_before, hi_after) are valid after `event`
+    struct Ahead
+    {
+        uint64_t hi_before, hi_after;
+        void *event;
+    };
+    void drain_ahead(void *stream, uint64_t below); // `stream` waits for the look-ahead launches that wrote rows below `below`
+    void *jump_stream_ = nullptr;
+    void *ev_main_ = nullptr;   // recorded on the caller's stream after ring operations issued there
+    bool main_dirty_ = false;   // ... which the look-ahead stream has not waited for yet
+    std::vector<Ahead> ahead_;  // oldest first
+    void *ev_strided_[StridedTable::kSlots] = {}; // after the look-ahead launch into a table of the sharded stream
+    bool strided_pending_[StridedTable::kSlots] = {};
+    std::vector<void *> ev_free_;
 };
 
 // Raw words of one mt19937_64(seed) stream (BSC / BEC draws, info words, ldpc_hip_mt64).
 class MtStream
 {
   public:
-    void reset(uint64_t seed) { st.reset(seed); }
+    void reset(uint64_t seed) { st.reset(seed), last_end_ = ~0ull; }
     uint64_t seed() const { return st.seed(); }
     // chunks per generator workgroup (1 or 4, kernels.hpp launch_mt_generate)
     void set_pack(int chunks_per_workgroup) { pack_ = chunks_per_workgroup; }
@@ -131,6 +152,7 @@ class MtStream
 
   private:
     int pack_ = 1;
+    uint64_t last_end_ = ~0ull; // word after the previous request
     DeviceBuffer raw_[2];
 };
 

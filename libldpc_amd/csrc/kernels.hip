@@ -32,6 +32,10 @@
 #include "device_math.hpp"
 #include "kernels.hpp"
 
+#ifndef LDPC_AMD_DECODE_PRIO
+#define LDPC_AMD_DECODE_PRIO 3
+#endif
+
 namespace ldpc_amd
 {
 
@@ -442,10 +446,24 @@ __device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b,
 // A degree-1 node (a leaf) is special: out - c2v = L_ch, so its v2c message is the channel ratio rho_ch itself — no
 // division, nothing to range-check; `lam` is then rho_ch, the decision total <= 0 is taken as lambda(c2v) >= rho_ch, and
 // the value returned (for the LLR output only) is lambda(total) = lambda(c2v) / rho_ch.
+// A 16-bit field of a register-held slot word addresses a message: as its element index or (BS, "byte slots": the
+// instantiations compiled for small codes, 8 * nnz < 2^16) as its byte offset — the field IS the address then, one
+// instruction per message less (the array's own offset rides in the instruction).
+template <bool BS>
+__device__ __forceinline__ double *slot_ptr(double *msg, uint32_t field)
+{
+    if constexpr (BS)
+        return reinterpret_cast<double *>(reinterpret_cast<char *>(msg) + field);
+    else
+        return msg + field;
+}
+
+template <bool BS = false>
 __device__ __forceinline__ double vn_leaf_ratio(double *msg, uint32_t slot, double rho)
 {
-    const double c = __builtin_fabs(msg[slot]);
-    msg[slot] = with_sign(rho, c >= rho ? 0x80000000u : 0u);
+    double *m = slot_ptr<BS>(msg, slot);
+    const double c = __builtin_fabs(*m);
+    *m = with_sign(rho, c >= rho ? 0x80000000u : 0u);
     return dm_ratio_div(c, rho); // dead code unless the caller wants the LLR
 }
 
@@ -485,18 +503,21 @@ __device__ __forceinline__ double vn_update_ratio(double *msg, const uint32_t *i
 // the same update for nodes of degree DV <= 2 whose slot indices the lane keeps in a register (two u16, kLlrRegs),
 // one node or two independent nodes (of two blocks) in lock step: no table load in front of the LDS round trip,
 // two chains in flight
-template <int DV>
+// (the packed word is made opaque every iteration: it is what stays live — unpacked indices hoisted out of the decode loop
+// would occupy registers for the whole kernel.  Making the caller's word opaque in place, without the copy, was tried: one
+// move less per block, and the headline kernel's allocation tips over, 20 bytes of scratch.)
+template <int DV, bool BS>
 __device__ __forceinline__ double vn_small_ratio(double *msg, uint32_t packed, double lam, uint32_t &escaped)
 {
     static_assert(DV >= 1 && DV <= 2, "register-held slot indices");
-    asm volatile("" : "+v"(packed)); // unpack here, every iteration: the packed word is what stays live
+    asm volatile("" : "+v"(packed));
     const uint32_t sl[2] = {packed & 0xFFFFu, packed >> 16};
     if constexpr (DV == 1)
-        return vn_leaf_ratio(msg, sl[0], lam);
+        return vn_leaf_ratio<BS>(msg, sl[0], lam);
     double c[DV];
 #pragma unroll
     for (int p = 0; p < DV; ++p)
-        c[p] = __builtin_fabs(msg[sl[p]]);
+        c[p] = __builtin_fabs(*slot_ptr<BS>(msg, sl[p]));
     double prod = lam;
 #pragma unroll
     for (int p = 0; p < DV; ++p)
@@ -508,12 +529,12 @@ __device__ __forceinline__ double vn_small_ratio(double *msg, uint32_t packed, d
     {
         const double o = tot * c[p];
         DM_RATIO_TRACK(escaped, o);
-        msg[sl[p]] = with_sign(o, sign);
+        *slot_ptr<BS>(msg, sl[p]) = with_sign(o, sign);
     }
     return prod;
 }
 
-template <int DV>
+template <int DV, bool BS>
 __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, uint32_t packed_b, double la, double lb,
                                                 uint32_t &escaped, double &pa, double &pb)
 {
@@ -523,11 +544,11 @@ __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, 
     double ca[DV], cb[DV];
 #pragma unroll
     for (int p = 0; p < DV; ++p)
-        ca[p] = __builtin_fabs(msg[sa[p]]), cb[p] = __builtin_fabs(msg[sb[p]]);
+        ca[p] = __builtin_fabs(*slot_ptr<BS>(msg, sa[p])), cb[p] = __builtin_fabs(*slot_ptr<BS>(msg, sb[p]));
     if constexpr (DV == 1) // two leaves: la, lb are their channel ratios (vn_leaf_ratio)
     {
-        msg[sa[0]] = with_sign(la, ca[0] >= la ? 0x80000000u : 0u);
-        msg[sb[0]] = with_sign(lb, cb[0] >= lb ? 0x80000000u : 0u);
+        *slot_ptr<BS>(msg, sa[0]) = with_sign(la, ca[0] >= la ? 0x80000000u : 0u);
+        *slot_ptr<BS>(msg, sb[0]) = with_sign(lb, cb[0] >= lb ? 0x80000000u : 0u);
         pa = dm_ratio_div(ca[0], la), pb = dm_ratio_div(cb[0], lb); // dead code unless the caller wants the LLRs
         return;
     }
@@ -542,8 +563,8 @@ __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, 
     {
         const double oa = ta * ca[p], ob = tb * cb[p];
         DM_RATIO_TRACK(escaped, oa), DM_RATIO_TRACK(escaped, ob);
-        msg[sa[p]] = with_sign(oa, sga);
-        msg[sb[p]] = with_sign(ob, sgb);
+        *slot_ptr<BS>(msg, sa[p]) = with_sign(oa, sga);
+        *slot_ptr<BS>(msg, sb[p]) = with_sign(ob, sgb);
     }
 }
 
@@ -551,25 +572,28 @@ __device__ __forceinline__ void vn_small_ratio2(double *msg, uint32_t packed_a, 
 // first — widest — VN block of every wave): no table load at all, every message read once.
 // TWICE: the words are unpacked once for the reads and once more for the writes — two instructions per edge against the
 // sixteen registers the unpacked addresses occupy across the product and the division otherwise (the hand-over kernel).
-template <int DV, bool TWICE = false>
-__device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32_t (&packed)[8], double lam, uint32_t &escaped)
+template <int DV, bool TWICE, bool BS>
+__device__ __forceinline__ double vn_update_ratio_regs(double *msg, uint32_t (&packed)[8], double lam, uint32_t &escaped)
 {
     // the words stay packed across iterations: without the barrier the compiler hoists all 16 unpacked indices out
     // of the decode loop and keeps them live for the whole kernel
     uint32_t pk[(DV + 1) / 2];
+    auto opaque = [&] {
 #pragma unroll
-    for (int i = 0; i < (DV + 1) / 2; ++i)
-    {
-        pk[i] = packed[i];
-        asm volatile("" : "+v"(pk[i]));
-    }
-    auto slot = [&](int p) { return (p & 1) ? pk[p >> 1] >> 16 : pk[p >> 1] & 0xFFFFu; };
+        for (int i = 0; i < (DV + 1) / 2; ++i)
+        {
+            pk[i] = packed[i];
+            asm volatile("" : "+v"(pk[i]));
+        }
+    };
+    opaque();
+    auto slot = [&](int p) { return slot_ptr<BS>(msg, (p & 1) ? pk[p >> 1] >> 16 : pk[p >> 1] & 0xFFFFu); };
     if constexpr (DV == 1)
-        return vn_leaf_ratio(msg, slot(0), lam);
+        return vn_leaf_ratio<BS>(msg, pk[0] & 0xFFFFu, lam);
     double c[DV];
 #pragma unroll
     for (int p = 0; p < DV; ++p)
-        c[p] = __builtin_fabs(msg[slot(p)]);
+        c[p] = __builtin_fabs(*slot(p));
     double prod = lam;
 #pragma unroll
     for (int p = 0; p < DV; ++p)
@@ -581,32 +605,24 @@ __device__ __forceinline__ double vn_update_ratio_regs(double *msg, const uint32
     const uint32_t sign = prod >= 1.0 ? 0x80000000u : 0u;
     const double tot = dm_ratio_div(1.0, prod);
     if constexpr (TWICE)
-    {
-#pragma unroll
-        for (int i = 0; i < (DV + 1) / 2; ++i)
-        {
-            pk[i] = packed[i];
-            asm volatile("" : "+v"(pk[i]));
-        }
-    }
+        opaque();
 #pragma unroll
     for (int p = 0; p < DV; ++p)
     {
         const double o = tot * c[p];
         DM_RATIO_TRACK(escaped, o);
-        msg[slot(p)] = with_sign(o, sign);
+        *slot(p) = with_sign(o, sign);
     }
     return prod;
 }
 
-template <bool TWICE = false>
-__device__ __forceinline__ double vn_block_ratio_regs(double *msg, const uint32_t (&packed)[8], int degree, double lam,
-                                                      uint32_t &escaped)
+template <bool TWICE, bool BS>
+__device__ __forceinline__ double vn_block_ratio_regs(double *msg, uint32_t (&packed)[8], int degree, double lam, uint32_t &escaped)
 {
     switch (degree) // wave-uniform, 1..16
     {
 #define LDPC_VN(D) \
-    case D: return vn_update_ratio_regs<D, TWICE>(msg, packed, lam, escaped);
+    case D: return vn_update_ratio_regs<D, TWICE, BS>(msg, packed, lam, escaped);
         LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
         LDPC_VN(9) LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15) LDPC_VN(16)
 #undef LDPC_VN
@@ -762,7 +778,7 @@ __device__ __forceinline__ void vn_update_llr2(bool store_hb, double *msg, uint8
 // The same updates with the slot indices in registers (kLlrRegs, min-sum: two u16 per word for nodes of degree <= 2, 16 x u16
 // in eight words for the wave's first block): no table load between the barrier and the first message read.  These run
 // the passes whose hard decisions nobody reads (no early termination: all but the last) and store none.
-template <int DV>
+template <int DV, bool BS>
 __device__ __forceinline__ void vn_small_llr2(double *msg, uint32_t packed_a, uint32_t packed_b, double L0, double L1, double &out0,
                                               double &out1)
 {
@@ -772,7 +788,7 @@ __device__ __forceinline__ void vn_small_llr2(double *msg, uint32_t packed_a, ui
     double c0[DV], c1[DV];
 #pragma unroll
     for (int p = 0; p < DV; ++p)
-        c0[p] = msg[s0[p]], c1[p] = msg[s1[p]];
+        c0[p] = *slot_ptr<BS>(msg, s0[p]), c1[p] = *slot_ptr<BS>(msg, s1[p]);
     out0 = L0, out1 = L1;
 #pragma unroll
     for (int p = 0; p < DV; ++p) // sequential sum in column file order
@@ -780,17 +796,38 @@ __device__ __forceinline__ void vn_small_llr2(double *msg, uint32_t packed_a, ui
 #pragma unroll
     for (int p = 0; p < DV; ++p)
     {
-        msg[s0[p]] = out0 - c0[p];
-        msg[s1[p]] = out1 - c1[p];
+        *slot_ptr<BS>(msg, s0[p]) = out0 - c0[p];
+        *slot_ptr<BS>(msg, s1[p]) = out1 - c1[p];
     }
 }
 
-template <int DV>
-__device__ __forceinline__ double vn_update_llr_regs(double *msg, const uint32_t (&packed)[8], double L)
+template <int DV, bool BS>
+__device__ __forceinline__ double vn_small_llr(double *msg, uint32_t packed, double L)
+{
+    static_assert(DV >= 1 && DV <= 2, "register-held slot indices");
+    asm volatile("" : "+v"(packed));
+    const uint32_t sl[2] = {packed & 0xFFFFu, packed >> 16};
+    double c[DV];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        c[p] = *slot_ptr<BS>(msg, sl[p]);
+    double out = L;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        out += c[p];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        *slot_ptr<BS>(msg, sl[p]) = out - c[p];
+    return out;
+}
+
+template <int DV, bool BS>
+__device__ __forceinline__ double vn_update_llr_regs(double *msg, uint32_t (&packed)[8], double L)
 {
     // the words stay packed across iterations (see vn_update_ratio_regs) and are unpacked once for the reads and once
     // more for the writes: sixteen unpacked addresses kept across the sum are sixteen registers
-    auto unpack = [&](uint32_t (&pk)[(DV + 1) / 2]) {
+    uint32_t pk[(DV + 1) / 2];
+    auto opaque = [&] {
 #pragma unroll
         for (int i = 0; i < (DV + 1) / 2; ++i)
         {
@@ -798,29 +835,30 @@ __device__ __forceinline__ double vn_update_llr_regs(double *msg, const uint32_t
             asm volatile("" : "+v"(pk[i]));
         }
     };
-    uint32_t pk[(DV + 1) / 2], pk2[(DV + 1) / 2];
-    unpack(pk);
+    auto slot = [&](int p) { return slot_ptr<BS>(msg, (p & 1) ? pk[p >> 1] >> 16 : pk[p >> 1] & 0xFFFFu); };
+    opaque();
     double c[DV];
 #pragma unroll
     for (int p = 0; p < DV; ++p)
-        c[p] = msg[(p & 1) ? pk[p >> 1] >> 16 : pk[p >> 1] & 0xFFFFu];
+        c[p] = *slot(p);
     double out = L;
 #pragma unroll
     for (int p = 0; p < DV; ++p) // sequential sum in column file order
         out += c[p];
-    unpack(pk2);
+    opaque();
 #pragma unroll
     for (int p = 0; p < DV; ++p)
-        msg[(p & 1) ? pk2[p >> 1] >> 16 : pk2[p >> 1] & 0xFFFFu] = out - c[p];
+        *slot(p) = out - c[p];
     return out;
 }
 
-__device__ __forceinline__ double vn_block_llr_regs(double *msg, const uint32_t (&packed)[8], int degree, double L)
+template <bool BS>
+__device__ __forceinline__ double vn_block_llr_regs(double *msg, uint32_t (&packed)[8], int degree, double L)
 {
     switch (degree) // wave-uniform, 1..16
     {
 #define LDPC_VN(D) \
-    case D: return vn_update_llr_regs<D>(msg, packed, L);
+    case D: return vn_update_llr_regs<D, BS>(msg, packed, L);
         LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
         LDPC_VN(9) LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15) LDPC_VN(16)
 #undef LDPC_VN
@@ -1013,6 +1051,10 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 #ifdef LDPC_AMD_PHASE_TRACE
     const uint64_t tr_entry = __builtin_amdgcn_s_memtime();
 #endif
+    // the decode waves win the SIMD's instruction arbitration over the slab kernel's waves of the next batch's noise, which
+    // share the compute units with them, are many and are in no hurry (rng_kernels.hip: the generator's serial chains run at
+    // this priority too)
+    __builtin_amdgcn_s_setprio(LDPC_AMD_DECODE_PRIO);
     const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
 
     if (tid == 0)
@@ -1036,6 +1078,10 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 #pragma unroll
     for (int w = 0; w <= VNB; ++w)
         my_idx[w] = 0;
+    // BS ("byte slots"): the instantiations compiled for small codes (the launcher: 8 * nnz < 2^16) keep byte offsets in
+    // the 16-bit fields instead of element indices (slot_ptr)
+    constexpr bool BS = LLR_MODE == kLlrRegs && (RATIO || MINSUM) && VNB != kMaxVnBlocksInRegs;
+    constexpr int kSlotShift = BS ? 3 : 0;
     auto pick_up_indices = [&] {
 #pragma unroll
         for (int w = 0; w < VNB; ++w)
@@ -1046,13 +1092,13 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                 {
                     const uint32_t *idx = P.vn_slot + b.idx_off + lane; // LDS-resident: every slot < 2^16
                     if (b.degree >= 1 && b.degree <= 2)
-                        my_idx[w] = idx[0] | (idx[(b.degree - 1) * b.count] << 16);
+                        my_idx[w] = (idx[0] << kSlotShift) | (idx[(b.degree - 1) * b.count] << (16 + kSlotShift));
                     else if (w == 0 && b.degree <= 16)
                     {
 #pragma unroll
                         for (int q = 0; q < 16; ++q)
                             if (q < b.degree)
-                                wide_idx[q >> 1] |= idx[q * b.count] << (16 * (q & 1));
+                                wide_idx[q >> 1] |= idx[q * b.count] << (16 * (q & 1) + kSlotShift);
                     }
                 }
             }
@@ -1195,8 +1241,8 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                 if (b.degree >= 1 && b.degree <= 2)
                 {
                     const double v0 = first_v2c(b, my_llr[w]);
-                    msg[my_idx[w] & 0xFFFFu] = v0;
-                    msg[my_idx[w] >> 16] = v0; // (degree 1: the same slot again)
+                    *slot_ptr<BS>(msg, my_idx[w] & 0xFFFFu) = v0;
+                    *slot_ptr<BS>(msg, my_idx[w] >> 16) = v0; // (degree 1: the same slot again)
                 }
                 else if (w == 0 && b.degree >= 3 && b.degree <= 16)
                 {
@@ -1204,7 +1250,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 #pragma unroll
                     for (int q = 0; q < 16; ++q)
                         if (q < b.degree)
-                            msg[(wide_idx[q >> 1] >> (16 * (q & 1))) & 0xFFFFu] = v0;
+                            *slot_ptr<BS>(msg, (wide_idx[q >> 1] >> (16 * (q & 1))) & 0xFFFFu) = v0;
                 }
                 else
                     from_table(b, my_llr[w]);
@@ -1332,11 +1378,11 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                         return;
                     double prod;
                     if (b.degree == 1)
-                        prod = vn_small_ratio<1>(msg, sl, lam, escaped);
+                        prod = vn_small_ratio<1, BS>(msg, sl, lam, escaped);
                     else if (b.degree == 2)
-                        prod = vn_small_ratio<2>(msg, sl, lam, escaped);
+                        prod = vn_small_ratio<2, BS>(msg, sl, lam, escaped);
                     else if (w == 0 && b.degree <= 16)
-                        prod = vn_block_ratio_regs<HANDOVER>(msg, wide_idx, b.degree, lam, escaped);
+                        prod = vn_block_ratio_regs<HANDOVER, BS>(msg, wide_idx, b.degree, lam, escaped);
                     else
                         prod = vn_block_ratio(msg, P.vn_slot + b.idx_off + lane, b.count, b.degree, lam, escaped);
                     put_llr(b, prod);
@@ -1366,9 +1412,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     {
                         double pa, pb;
                         if (b0.degree == 1)
-                            vn_small_ratio2<1>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], escaped, pa, pb);
+                            vn_small_ratio2<1, BS>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], escaped, pa, pb);
                         else
-                            vn_small_ratio2<2>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], escaped, pa, pb);
+                            vn_small_ratio2<2, BS>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], escaped, pa, pb);
                         put_llr(b0, pa);
                         put_llr(b1, pb);
                     }
@@ -1459,12 +1505,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     return;
                 double out;
                 if (b.degree >= 1 && b.degree <= 2)
-                {
-                    const uint32_t pk[8] = {my_idx[w], 0, 0, 0, 0, 0, 0, 0};
-                    out = b.degree == 1 ? vn_update_llr_regs<1>(msg, pk, L) : vn_update_llr_regs<2>(msg, pk, L);
-                }
+                    out = b.degree == 1 ? vn_small_llr<1, BS>(msg, my_idx[w], L) : vn_small_llr<2, BS>(msg, my_idx[w], L);
                 else if (w == 0 && b.degree >= 3 && b.degree <= 16)
-                    out = vn_block_llr_regs(msg, wide_idx, b.degree, L);
+                    out = vn_block_llr_regs<BS>(msg, wide_idx, b.degree, L);
                 else
                     out = vn_block_llr_lean(msg, hb, P.vn_slot + b.idx_off + lane, b.count, b.degree, L, false);
                 if constexpr (WANT_LLR)
@@ -1491,9 +1534,9 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     {
                         double o0, o1;
                         if (b0.degree == 1)
-                            vn_small_llr2<1>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], o0, o1);
+                            vn_small_llr2<1, BS>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], o0, o1);
                         else
-                            vn_small_llr2<2>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], o0, o1);
+                            vn_small_llr2<2, BS>(msg, my_idx[w], my_idx[w + 1], my_llr[w], my_llr[w + 1], o0, o1);
                         if constexpr (WANT_LLR)
                         {
                             out_llr[P.rank_col[b0.first + lane]] = o0;
@@ -2064,7 +2107,8 @@ int launch_decode_impl(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, vo
         k = want_llr ? decode_kernel<false, true, LDS_RESIDENT, MAXD, LLR_MODE, false>
                      : decode_kernel<false, false, LDS_RESIDENT, MAXD, LLR_MODE, false>;
     }
-    [[maybe_unused]] const bool few_vn_blocks = a.plan.vn_work_stride <= kW5VnBlocks;
+    // the instantiations for small codes: at most kW5VnBlocks VN blocks per wave, message byte offsets within 16 bits
+    [[maybe_unused]] const bool few_vn_blocks = a.plan.vn_work_stride <= kW5VnBlocks && 8 * a.plan.nnz < 65536;
     if constexpr (LDS_RESIDENT && MAXD == 4 && LLR_MODE == kLlrRegs)
         if (!want_llr && few_vn_blocks)
         {

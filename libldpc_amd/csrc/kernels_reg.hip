@@ -100,6 +100,7 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
     const DevPlan &P = a.plan;
     const int nc = P.nc;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_amdgcn_s_setprio(3); // ahead of the noise generator's waves in the SIMD's instruction arbitration (kernels.hip)
     uint64_t frame = blockIdx.x;
     if (a.redo_count_in) // second pass: only the frames the ratio form handed back
     {

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
     const DevPlan &P = a.plan;
     const int nc = P.nc;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_amdgcn_s_setprio(3); // ahead of the noise generator's waves in the SIMD's instruction arbitration (kernels.hip)
     uint32_t *vote = reinterpret_cast<uint32_t *>(lds + R.lds_entries);
     if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>((double __attribute__((address_space(3))) *)lds)) != 0)
         __builtin_trap(); // the dynamic LDS array does not start at 0: the packed addresses would be wrong

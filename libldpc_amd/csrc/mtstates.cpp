@@ -107,6 +107,12 @@ void StateRing::ensure(uint64_t c_lo, uint64_t c_hi, std::vector<StateOp> &ops)
     if (!valid_ || c_lo < lo_ || c_lo > hi_)
         seek(c_lo, ops);
     req_lo_ = c_lo, req_hi_ = c_hi;
+    grow(c_hi, ops);
+}
+
+// rows of the chunks [hi_, c_hi): the newest w rows advanced by w chunks, w the largest power of two the ring holds
+void StateRing::grow(uint64_t c_hi, std::vector<StateOp> &ops)
+{
     while (hi_ < c_hi)
     {
         const uint64_t avail = std::min<uint64_t>(hi_ - lo_, kWindow);
@@ -122,36 +128,65 @@ void StateRing::ensure(uint64_t c_lo, uint64_t c_hi, std::vector<StateOp> &ops)
     }
 }
 
-void StridedTable::position(uint64_t first, uint32_t n, uint64_t stride, std::vector<StateOp> &ops)
+void StateRing::extend_to(uint64_t c_hi, std::vector<StateOp> &ops)
+{
+    if (!valid_ || hi_ <= lo_)
+        return;
+    if (req_hi_ > req_lo_) // (row c % kRows is overwritten by chunk c + kRows)
+        c_hi = std::min(c_hi, req_lo_ + kRows);
+    grow(c_hi, ops);
+}
+
+uint32_t StridedTable::position(uint64_t first, uint32_t n, uint64_t stride, std::vector<StateOp> &ops)
 {
     if (n == 0 || n > kMaxRows || stride == 0)
         throw std::runtime_error("sharded mt19937_64 table: bad geometry");
-    const uint32_t mod = kMaxRows + 2, sa = kMaxRows, sb = kMaxRows + 1;
+    const uint32_t mod = kTotalRows, sa = kSlots * kMaxRows, sb = kSlots * kMaxRows + 1;
     if (valid_ && n == n_ && stride == stride_)
     {
         if (first == first_)
-            return;
-        if (first == first_ + stride_) // the step every rank takes: n tasks, one polynomial, in place
+            return slot_ * kMaxRows;
+        if (first == first_ + stride_) // the step every rank takes: n tasks, one polynomial, into the next table
         {
-            ops.push_back({StateOp::kJump, 0, 0, n, mod, stride});
+            const uint32_t next = (slot_ + 1) % kSlots;
+            if (ahead_ == 0)
+                ops.push_back({StateOp::kJump, slot_ * kMaxRows, next * kMaxRows, n, mod, stride});
+            else
+                --ahead_;
+            slot_ = next;
             first_ = first;
-            return;
+            return slot_ * kMaxRows;
         }
     }
+    ahead_ = 0; // (whatever the other tables hold is no longer what comes next)
+    const uint32_t base = slot_ * kMaxRows;
     uint64_t d = first;
     if (valid_ && first >= first_ && __builtin_popcountll(first - first_) < __builtin_popcountll(first) + 1)
     {
-        ops.push_back({StateOp::kCopy, 0, sa, 1, 0, 0});
+        ops.push_back({StateOp::kCopy, base, sa, 1, 0, 0});
         d = first - first_;
     }
     else
         ops.push_back({StateOp::kUpload0, 0, sa, 1, 0, 0});
     const uint32_t at = jump_bits(d, sa, sb, mod, ops);
-    ops.push_back({StateOp::kCopy, at, 0, 1, 0, 0});
+    ops.push_back({StateOp::kCopy, at, base, 1, 0, 0});
     for (uint32_t w = 1; w < n; w *= 2)
-        ops.push_back({StateOp::kJump, 0, w, std::min(w, n - w), mod, w});
+        ops.push_back({StateOp::kJump, base, base + w, std::min(w, n - w), mod, w});
     valid_ = true;
     first_ = first, n_ = n, stride_ = stride;
+    return base;
+}
+
+void StridedTable::look_ahead(std::vector<StateOp> &ops)
+{
+    if (!valid_)
+        return;
+    while (ahead_ + 1 < kSlots) // (the table in use is never a destination)
+    {
+        const uint32_t src = (slot_ + ahead_) % kSlots, dst = (slot_ + ahead_ + 1) % kSlots;
+        ops.push_back({StateOp::kJump, src * kMaxRows, dst * kMaxRows, n_, kTotalRows, stride_});
+        ++ahead_;
+    }
 }
 
 } // namespace ldpc_amd

@@ -53,12 +53,16 @@ class StateRing
     void invalidate() { valid_ = false, req_lo_ = req_hi_ = 0; }
     // append the operations after which row c % kRows holds the start state of chunk c for every c in [c_lo, c_hi)
     void ensure(uint64_t c_lo, uint64_t c_hi, std::vector<StateOp> &ops);
+    // look-ahead: append the operations that make the rows of the chunks up to c_hi valid as well (never at the expense of a
+    // row the previous request reads; nothing when the ring holds no state yet).  The previous request stays what it was.
+    void extend_to(uint64_t c_hi, std::vector<StateOp> &ops);
     uint64_t lo() const { return lo_; }
     uint64_t hi() const { return hi_; }
     bool valid() const { return valid_; }
 
   private:
     void seek(uint64_t c, std::vector<StateOp> &ops);
+    void grow(uint64_t c_hi, std::vector<StateOp> &ops);
     bool valid_ = false;
     uint64_t lo_ = 0, hi_ = 0; // rows of chunks [lo_, hi_) are valid
     uint64_t req_lo_ = 0, req_hi_ = 0; // the previous request
@@ -67,17 +71,26 @@ class StateRing
 class StridedTable
 {
   public:
-    static constexpr uint32_t kMaxRows = 4096; // rows 0 .. n-1, two scratch rows follow (n, n + 1)
-    void invalidate() { valid_ = false; }
-    // append the operations after which row i holds the start state of chunk first + i, i < n; the table then advances by
-    // `stride` chunks per advance().  Re-used when the geometry is unchanged and `first` is where the table stands or one
-    // stride further.
-    void position(uint64_t first, uint32_t n, uint64_t stride, std::vector<StateOp> &ops);
+    static constexpr uint32_t kMaxRows = 4096;                       // rows of a table
+    static constexpr uint32_t kSlots = 3;                            // tables: the one in use and up to two steps of look-ahead
+    static constexpr uint32_t kTotalRows = kSlots * kMaxRows + 2;    // ... and two scratch rows
+    void invalidate() { valid_ = false, ahead_ = 0; }
+    // append the operations after which row base + i holds the start state of chunk first + i, i < n; returns base (a
+    // multiple of kMaxRows).  Re-used when the geometry is unchanged and `first` is where the table stands or one stride
+    // further: the step every rank takes costs ONE launch of n tasks from one table into the next — or nothing at all
+    // when look_ahead() planned that launch already.
+    uint32_t position(uint64_t first, uint32_t n, uint64_t stride, std::vector<StateOp> &ops);
+    // look-ahead: append the launches (one per step, each into a table of its own) that bring the tables of the next TWO
+    // steps into being: planned two steps before its table is read, a launch has a whole step to run beside the generator
+    void look_ahead(std::vector<StateOp> &ops);
+    uint32_t ahead() const { return ahead_; }
     uint64_t first() const { return first_; }
     uint32_t rows() const { return n_; }
 
   private:
     bool valid_ = false;
+    uint32_t ahead_ = 0; // the next `ahead_` tables after the one in use hold (or are being given) the tables of the next steps
+    uint32_t slot_ = 0;
     uint64_t first_ = 0, stride_ = 0;
     uint32_t n_ = 0;
 };

@@ -40,13 +40,16 @@ def test_chunk_state_ring_bookkeeping(lib):
     ring, libldpc_amd/csrc/mtstates.hpp: far more sequential requests than the ring has rows — a long Monte-Carlo run of
     one-chunk batches (BSC/BEC batches, the encoder's info stream), headline-sized batches, requests as wide as the
     window — must leave every requested chunk with a valid row, never read a row that holds nothing, and in steady state
-    cost as many jump-ahead tasks as chunks were consumed (no doubling bursts)."""
+    cost as many jump-ahead tasks as chunks were consumed (no doubling bursts), with the engine's look-ahead extension
+    (StateRing::extend_to) interleaved."""
     win, bad = 2048, 2**64 - 1
     for first, per, n in [(0, 1, 3 * 4096 + 7), (0, 2, 2 * 4096), (0, 82, 600), (5, 64, 2000), (0, win, 9), (123456, 1, win + 50),
                           (0, 7, 4000), (4095, 1, 10), (4096, 1, 10), (0, win - 1, 7), (10**12 + 3, 83, 100)]:
         tasks = lib.ldpc_hip_selftest_chunk_table(first, per, n, 0)
         assert tasks != bad, (first, per, n)
-        assert tasks <= per * n + 64 + 12, (first, per, n, tasks)  # + the seek to `first` (one task per set bit)
+        # + the seek to `first` (one task per set bit) + what the look-ahead (two requests in three are followed by the
+        # engine's extension to the next request but one) has computed beyond the last request
+        assert tasks <= per * (n + 2) + 2 + 64 + 12, (first, per, n, tasks)
     assert lib.ldpc_hip_selftest_chunk_table(0, win + 1, 1, 0) == bad  # wider than the window: refused, not overrun
     # a rank of a sharded BSC / BEC stream: equal requests a fixed distance apart -> one launch per request, whatever the gap
     per, n = 65, 80

@@ -119,7 +119,7 @@ def main():
     for k, v in merged.items():
         w(f"| {k} | {v:.2f} |" + (f" {meas.get(k, float('nan')):.2f} |" if meas else ""))
     routines = sum(merged.values())
-    w(f"| **all VALU, routines** | **{routines:.2f}** |" + (f" {meas.get('all_valu', float('nan')):.2f} (whole kernel) |" if meas else ""))
+    w(f"| **all VALU, routines** | **{routines:.2f}** |" + (f" {meas.get('all_valu', args.measured_all_valu or float('nan')):.2f} (whole kernel) |" if meas else ""))
     if args.measured_all_valu:
         rest = args.measured_all_valu - routines
         w("")

@@ -64,7 +64,7 @@ __global__ void probe_vn1x2(double *msg, uint32_t *out, double la, double lb)
     uint32_t esc = out[0], ia = out[1 + threadIdx.x], ib = out[65 + threadIdx.x];
     double pa, pb;
     PROBE_BEGIN;
-    vn_small_ratio2<1>(lds, ia, ib, la, lb, esc, pa, pb);
+    vn_small_ratio2<1, true>(lds, ia, ib, la, lb, esc, pa, pb);
     PROBE_END;
     out[threadIdx.x] = esc;
 }
@@ -74,7 +74,7 @@ __global__ void probe_vn2x2(double *msg, uint32_t *out, double la, double lb)
     uint32_t esc = out[0], ia = out[1 + threadIdx.x], ib = out[65 + threadIdx.x];
     double pa, pb;
     PROBE_BEGIN;
-    vn_small_ratio2<2>(lds, ia, ib, la, lb, esc, pa, pb);
+    vn_small_ratio2<2, true>(lds, ia, ib, la, lb, esc, pa, pb);
     PROBE_END;
     out[threadIdx.x] = esc;
 }
@@ -86,7 +86,7 @@ __global__ void probe_vn15(double *msg, uint32_t *out, double lam)
     for (int i = 0; i < 8; ++i)
         pk[i] = out[1 + 64 * i + threadIdx.x];
     PROBE_BEGIN;
-    const double prod = vn_update_ratio_regs<15>(lds, pk, lam, esc);
+    const double prod = vn_update_ratio_regs<15, false, true>(lds, pk, lam, esc);
     PROBE_END;
     out[threadIdx.x] = esc ^ hi_word(prod);
 }

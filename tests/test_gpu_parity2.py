@@ -143,3 +143,34 @@ def test_cli_binary_awgn_vs_reference_cli(golden_sim, tmp_path):
         for g, r in zip(got[1:], ref[1:]):
             assert (g[0], g[1], g[3], g[4]) == (r[0], r[1], r[3], r[4]), (name, g, r)  # x, FER, frames, avg_iter
             assert abs(float(g[2]) - float(r[2])) <= 0.02 * float(r[2]), (name, g, r)   # BER: failing frames' wrong bits
+
+
+@pytest.mark.parametrize("chan,x", [("AWGN", -4.0), ("BSC", 0.24)])
+def test_irregular_batches_with_look_ahead(dec, chan, x):
+    """The chunk start states of the noise stream are computed two batches ahead of use on a stream of their own, from a
+    guess of where the next batches will read (engine.cpp, MtDevice::prefetch_ring).  Batches whose sizes jump about — a
+    frame, a hundred thousand frames, a handful — make that guess wrong in both directions, a new seed or channel point
+    invalidates what is in flight, a skip moves the reader past it: frame f must stay the f-th frame of the stream.  The
+    same ≈ 290 000 frames once in irregular pieces (with a re-seeded detour in the middle) and once in one call; the last
+    frames of the irregular run against the det-mode oracle."""
+    sizes = [70000, 3, 40000, 1, 90000, 2000, 5, 65536, 17, 23000]
+    kw = dict(decoding="BP_MS", iterations=3, early_term=True, want=("iters", "bit_errors"))
+    dec.stream_begin(chan, 11, x)
+    parts = []
+    for i, n in enumerate(sizes):
+        parts.append(dec.stream_decode(n, **kw))
+        if i == 4:  # a detour on another seed and point, then back to where the stream stood (skip = RNG only)
+            at = dec.stream_frame
+            dec.stream_begin(chan, 12, x * 0.9)
+            dec.stream_decode(3000, **kw)
+            dec.stream_begin(chan, 11, x)
+            dec.stream_skip(at)
+    total = sum(sizes)
+    dec.stream_begin(chan, 11, x)
+    whole = dec.stream_decode(total, **kw)
+    assert np.array_equal(np.concatenate([p["iters"] for p in parts]), whole["iters"])
+    assert np.array_equal(np.concatenate([p["bit_errors"] for p in parts]), whole["bit_errors"])
+    tail = 64
+    o = orc.Code(orc.H_TXT).run_frames(chan, x, seed=11, skip=total - tail, count=tail, math=orc.MATH_DET, min_sum=True, iters=3,
+                                       want_vectors=False)
+    assert np.array_equal(whole["iters"][-tail:], o["iters"]) and np.array_equal(whole["bit_errors"][-tail:], o["bit_errors"])

@@ -62,13 +62,19 @@ def _compile(src):
             if p.returncode:
                 sys.stderr.write(p.stderr)
             else:  # diagnostics other than the remarks (each remark is followed by a source line and a caret line)
-                skip = 0
+                skip, held = 0, []
                 for l in lines:
+                    if l.startswith("In file included from "):
+                        held.append(l)  # the include trail of the next diagnostic: shown unless that is a remark
+                        continue
                     if l in remarks:
-                        skip = 2
+                        skip, held = 2, []
                     elif skip and ("|" in l[:8] or not l.strip()):
                         skip -= 1
                     elif "remark generated" not in l and "remarks generated" not in l:
+                        for h in held:
+                            sys.stderr.write(h + "\n")
+                        held = []
                         sys.stderr.write(l + "\n")
             if p.returncode:
                 raise subprocess.CalledProcessError(p.returncode, cmd)

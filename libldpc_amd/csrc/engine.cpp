@@ -75,22 +75,30 @@ struct OutStage
         items.push_back({user, d, bytes});
         return static_cast<T *>(d);
     }
-    // small results go through page-locked memory: a device-to-pageable copy is a blocking staged copy per call,
-    // which is most of a single-frame decode()'s latency
-    void flush(hipStream_t s, PinnedBuffer *pin = nullptr)
+    size_t pinned_bytes() const
     {
         size_t total = 0;
         for (auto &i : items)
             total += (i.bytes + 63) & ~size_t(63);
+        return total;
+    }
+    // small results go through page-locked memory: a device-to-pageable copy is a blocking staged copy per call,
+    // which is most of a single-frame decode()'s latency.  `word` (optional): a device word that rides along and is
+    // returned — the results are delivered, the items kept, so that the caller can deliver them again after more launches.
+    uint32_t flush(hipStream_t s, PinnedBuffer *pin = nullptr, const uint32_t *word = nullptr)
+    {
+        const size_t total = pinned_bytes();
         if (pin && total && total <= kPinnedLimit)
         {
-            char *h = static_cast<char *>(pin->reserve(total));
+            char *h = static_cast<char *>(pin->reserve(total + 64));
             size_t off = 0;
             for (auto &i : items)
             {
                 check(hipMemcpyAsync(h + off, i.dev, i.bytes, hipMemcpyDeviceToHost, s), "copy out");
                 off += (i.bytes + 63) & ~size_t(63);
             }
+            if (word)
+                check(hipMemcpyAsync(h + total, word, 4, hipMemcpyDeviceToHost, s), "copy out");
             check(hipStreamSynchronize(s), "sync");
             off = 0;
             for (auto &i : items)
@@ -98,14 +106,23 @@ struct OutStage
                 std::memcpy(i.host, h + off, i.bytes);
                 off += (i.bytes + 63) & ~size_t(63);
             }
+            if (word)
+            {
+                uint32_t w;
+                std::memcpy(&w, h + total, 4);
+                return w;
+            }
             items.clear();
-            return;
+            return 0;
         }
+        if (word)
+            throw std::runtime_error("OutStage: a ride-along word needs the page-locked path");
         for (auto &i : items)
             check(hipMemcpyAsync(i.host, i.dev, i.bytes, hipMemcpyDeviceToHost, s), "copy out");
         if (!items.empty())
             check(hipStreamSynchronize(s), "sync");
         items.clear();
+        return 0;
     }
     static constexpr size_t kPinnedLimit = 1 << 20;
 };
@@ -790,6 +807,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
     // Without early termination the LDS-resident decoder still starts every frame in the ratio form and hands it over
     // to the LLR-domain form at an iteration boundary when its totals near the edge of the box (detmath.h "Hand-over").
     const bool handover = !p.early_term && plan_.lds_ok;
+    bool later_stages = true;
     if (!p.min_sum && (p.early_term || handover) && p.iterations > 0 && plan_.max_cn_degree <= kMaxCnDegree &&
         !std::getenv("LDPC_AMD_NO_RATIO"))
     {
@@ -828,7 +846,20 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
 #endif
         a.redo_count = nullptr, a.redo_list = nullptr, a.redo_iter = nullptr;
         a.redo_count_in = redo, a.redo_list_in = redo + 1;
-        if (handover)
+        // A handful of frames for a caller who waits for host results anyway (the reference's decode(): one frame per call):
+        // the results of the first launch and the number of frames it handed back travel to the host together; the later
+        // launches — two more dispatches and a memset, a fifth of such a call's latency, for lists that are almost always
+        // empty — are issued only when that number is not zero, and the results delivered again.
+        const size_t pinned = st.pinned_bytes();
+        if (n <= 16 && pinned && pinned <= OutStage::kPinnedLimit && !handover && a.mode == kModeLlr &&
+            st.flush(s, &pin_out_, redo) == 0)
+        {
+            later_stages = false;
+            st.items.clear(); // (delivered)
+        }
+        if (!later_stages)
+            ;
+        else if (handover)
             a.redo_iter_in = redo + 1 + n;
         else if (plan_.lds_ok)
         {
@@ -847,7 +878,8 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
             a.redo_count_in = redo2, a.redo_list_in = redo2 + 1;
         }
     }
-    launch();
+    if (later_stages)
+        launch();
     a.redo_count_in = nullptr, a.redo_list_in = nullptr, a.redo_iter_in = nullptr, a.ws_handover = nullptr;
     prof_mark(0, s);
     if (a.mode == kModeAwgn && a.pairs_buffer >= 0 && ev_pairs_free_[a.pairs_buffer])

@@ -1279,11 +1279,10 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             uint32_t bad = 0;
             // LDS-resident decoder with early termination: shared-reciprocal check nodes (detmath.h; the oracle applies the
             // same rule, a property of the code)
-#ifdef LDPC_AMD_HANDOVER_SHARED // experiment: the shared-reciprocal check nodes in the hand-over kernel as well
-            constexpr bool SH = LDS_RESIDENT && !SEPARATE;
-#else
+            // (not in the hand-over kernel: its frames iterate on after they have converged, the denominator products
+            // overflow before the hand-over threshold is reached, and every overflow is a frame decoded again — measured:
+            // 31.7 ms per batch instead of 13.2)
             constexpr bool SH = LDS_RESIDENT && !HANDOVER && !SEPARATE;
-#endif
             // blocks two at a time where they match (plan.cpp deals each wave's blocks in degree order); both
             // descriptors arrive with one scalar load (plan.cpp, cn_work_desc)
             for (int w = 0; w < P.cn_work_stride; w += 2)

@@ -1,6 +1,6 @@
 """Lean workload driver for the rocprofv3 passes (no torch: the profiler sees only the library's kernels).
 
-usage: python3 tools/pmc_probe.py --config {2,2n,3,4,4n,5,5bec} [--steps 3] [--warmup 2] [--batch B]
+usage: python3 tools/pmc_probe.py --config {2,2n,3,4,4n,5,5bec} [--steps 3] [--warmup 2] [--batch B] [--x POINT]
 Runs warmup + steps batches of the BASELINE.json configuration through ldpc_hip_stream_decode (outputs: per-frame
 iteration counts and bit errors to host buffers) and prints one JSON line {config, frames, iterations_executed,
 edge_updates, kernel_ms}."""
@@ -17,8 +17,11 @@ ap.add_argument("--config", default="2")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--batch", type=int, default=0)
+ap.add_argument("--x", type=float, default=None, help="channel point instead of the configuration's (tools/valu_fit.sh)")
 args = ap.parse_args()
-w = workloads.get(args.config)
+w = dict(workloads.get(args.config))
+if args.x is not None:
+    w["x"] = args.x
 B = args.batch or w["batch"]
 d = HipDecoder(workloads.code_path(w))
 d.set_profiling(True)

@@ -29,15 +29,28 @@ __device__ __forceinline__ void channel_init(const DecodeArgs &a, uint64_t frame
     }
     else
     {
-        for (int r = tid; r < nc; r += kThreads)
+        // the kinds of eight ranks per load (the table is padded to a multiple of eight, plan.cpp): one round trip for codes
+        // of up to 8 x the workgroup's threads variable nodes, where a rank per trip of the loop was nc / threads dependent
+        // ones at the head of every frame
+        for (int r8 = 8 * tid; r8 < nc; r8 += 8 * kThreads)
         {
-            uint8_t k = P.rank_kind[r];
-            if (k == 1)
-                llr[r] = 0.0; // punctured = erasure
-            else if (k == 2)
-                llr[r] = a.shorten_llr;
-            else if (k == 3)
-                llr[r] = 0.0; // never written by the channel: keeps the decoder's initial zero
+            const uint64_t kinds = *reinterpret_cast<const uint64_t *>(P.rank_kind + r8);
+            if (kinds == 0)
+                continue; // (eight transmitted bits: the channel writes them)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+            {
+                const uint32_t k = static_cast<uint32_t>(kinds >> (8 * e)) & 0xFFu;
+                const int r = r8 + e;
+                if (r >= nc)
+                    break;
+                if (k == 1)
+                    llr[r] = 0.0; // punctured = erasure
+                else if (k == 2)
+                    llr[r] = a.shorten_llr;
+                else if (k == 3)
+                    llr[r] = 0.0; // never written by the channel: keeps the decoder's initial zero
+            }
         }
         if (a.mode == kModeAwgn)
         {
@@ -65,41 +78,75 @@ __device__ __forceinline__ void channel_init(const DecodeArgs &a, uint64_t frame
                 while (j0 + 1 < a.n_slabs && rel_lo >= cum[j0 + 1])
                     ++j0;
             }
-            for (uint64_t q = q_lo + tid; q <= q_hi; q += kThreads)
+            // The pairs of a frame in groups of kGroup per thread: the loads of a group — the pair words from the slabs and
+            // the rank of each normal's bit, which depends on the pair's index only — all go out before anything waits for
+            // one of them.  (One pair per trip of a plain loop: a trip's first use sits in front of the next trip's load, two
+            // or three round trips to memory one after the other at the head of every frame — and a frame holds its place
+            // on the CU for as long as its prologue takes, whatever the other frames there do meanwhile.)
+            constexpr int kGroup = 2;
+            for (uint64_t q0 = q_lo + tid; q0 <= q_hi; q0 += static_cast<uint64_t>(kGroup) * kThreads)
             {
-                const uint64_t rel = q - a.pair_origin;
-                uint32_t j;
-                uint64_t base;
-                if (window)
-                {
-                    const uint32_t k = (rel >= c1) + (rel >= c2);
-                    j = jb + k;
-                    base = k == 0 ? c0 : (k == 1 ? c1 : c2);
-                }
-                else
-                {
-                    j = j0;
-                    while (j + 1 < a.n_slabs && rel >= a.slab_cum[j + 1])
-                        ++j;
-                    base = a.slab_cum[j];
-                }
-                // streamed once: non-temporal, so that the 8 KB of a frame do not push the slot tables — which every
-                // frame that starts on this CU reads — out of the CU's 32 KB vector cache
-                const uint64_t *pq = a.pairs + static_cast<uint64_t>(j) * a.slab_words + 2 * (rel - base);
-                ulonglong2 pp;
-                pp.x = __builtin_nontemporal_load(pq), pp.y = __builtin_nontemporal_load(pq + 1);
-                const double nrm[2] = {dm_from_bits(pp.x), dm_from_bits(pp.y)};
+                ulonglong2 pp[kGroup];
+                uint32_t rk[kGroup][2];
+                int xb[kGroup][2];
 #pragma unroll
-                for (int k = 0; k < 2; ++k)
+                for (int u = 0; u < kGroup; ++u)
                 {
-                    uint64_t g = 2 * q + k;
-                    if (g < g0 || g >= g0 + nct)
+                    const uint64_t q = q0 + static_cast<uint64_t>(u) * kThreads;
+                    pp[u].x = pp[u].y = 0;
+                    rk[u][0] = rk[u][1] = 0, xb[u][0] = xb[u][1] = 0;
+                    if (q > q_hi)
                         continue;
-                    int i = static_cast<int>(g - g0);
-                    double noise = nrm[k] * a.sigma + 0.0;
-                    double xs = cw ? static_cast<double>(1 - 2 * static_cast<int>(cw[P.bit_pos[i]])) : 1.0;
-                    double y = noise + xs;
-                    llr[P.tx_rank[i]] = 2 * y / a.sigma2;
+                    const uint64_t rel = q - a.pair_origin;
+                    uint32_t j;
+                    uint64_t base;
+                    if (window)
+                    {
+                        const uint32_t k = (rel >= c1) + (rel >= c2);
+                        j = jb + k;
+                        base = k == 0 ? c0 : (k == 1 ? c1 : c2);
+                    }
+                    else
+                    {
+                        j = j0;
+                        while (j + 1 < a.n_slabs && rel >= a.slab_cum[j + 1])
+                            ++j;
+                        base = a.slab_cum[j];
+                    }
+                    // streamed once: non-temporal, so that the 8 KB of a frame do not push the slot tables — which every
+                    // frame that starts on this CU reads — out of the CU's 32 KB vector cache
+                    const uint64_t *pq = a.pairs + static_cast<uint64_t>(j) * a.slab_words + 2 * (rel - base);
+                    pp[u].x = __builtin_nontemporal_load(pq), pp[u].y = __builtin_nontemporal_load(pq + 1);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                    {
+                        const uint64_t g = 2 * q + k;
+                        if (g < g0 || g >= g0 + nct)
+                            continue;
+                        const int i = static_cast<int>(g - g0);
+                        rk[u][k] = P.tx_rank[i];
+                        if (cw)
+                            xb[u][k] = static_cast<int>(cw[P.bit_pos[i]]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kGroup; ++u)
+                {
+                    const uint64_t q = q0 + static_cast<uint64_t>(u) * kThreads;
+                    if (q > q_hi)
+                        continue;
+                    const double nrm[2] = {dm_from_bits(pp[u].x), dm_from_bits(pp[u].y)};
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                    {
+                        const uint64_t g = 2 * q + k;
+                        if (g < g0 || g >= g0 + nct)
+                            continue;
+                        const double noise = nrm[k] * a.sigma + 0.0;
+                        const double xs = cw ? static_cast<double>(1 - 2 * xb[u][k]) : 1.0;
+                        const double y = noise + xs;
+                        llr[rk[u][k]] = 2 * y / a.sigma2;
+                    }
                 }
             }
         }

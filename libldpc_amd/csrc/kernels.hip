@@ -616,6 +616,8 @@ __device__ __forceinline__ double vn_update_ratio_regs(double *msg, uint32_t (&p
     return prod;
 }
 
+// (the instantiations for small codes, BS, take such nodes up to degree 15: the sixteenth message is the two registers the
+// headline kernel does not have — its callers send a node of degree 16 through the slot table, kWideMax)
 template <bool TWICE, bool BS>
 __device__ __forceinline__ double vn_block_ratio_regs(double *msg, uint32_t (&packed)[8], int degree, double lam, uint32_t &escaped)
 {
@@ -624,8 +626,12 @@ __device__ __forceinline__ double vn_block_ratio_regs(double *msg, uint32_t (&pa
 #define LDPC_VN(D) \
     case D: return vn_update_ratio_regs<D, TWICE, BS>(msg, packed, lam, escaped);
         LDPC_VN(1) LDPC_VN(2) LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8)
-        LDPC_VN(9) LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15) LDPC_VN(16)
+        LDPC_VN(9) LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15)
 #undef LDPC_VN
+    case 16:
+        if constexpr (!BS)
+            return vn_update_ratio_regs<16, TWICE, BS>(msg, packed, lam, escaped);
+        return lam;
     default: return lam;
     }
 }
@@ -1082,6 +1088,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     // the 16-bit fields instead of element indices (slot_ptr)
     constexpr bool BS = LLR_MODE == kLlrRegs && (RATIO || MINSUM) && VNB != kMaxVnBlocksInRegs;
     constexpr int kSlotShift = BS ? 3 : 0;
+    constexpr int kWideMax = BS ? 15 : 16; // widest node whose slot indices the lane keeps in registers (vn_block_ratio_regs)
     auto pick_up_indices = [&] {
 #pragma unroll
         for (int w = 0; w < VNB; ++w)
@@ -1093,7 +1100,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     const uint32_t *idx = P.vn_slot + b.idx_off + lane; // LDS-resident: every slot < 2^16
                     if (b.degree >= 1 && b.degree <= 2)
                         my_idx[w] = (idx[0] << kSlotShift) | (idx[(b.degree - 1) * b.count] << (16 + kSlotShift));
-                    else if (w == 0 && b.degree <= 16)
+                    else if (w == 0 && b.degree <= kWideMax)
                     {
 #pragma unroll
                         for (int q = 0; q < 16; ++q)
@@ -1147,25 +1154,36 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     my_llr[VNB] = 0.0;
     if constexpr (LLR_MODE == kLlrRegs)
     {
+        // every block's LLR first, then every block's arithmetic, branch-free: seven exponentials in lock step instead of
+        // seven load -> exponential -> division chains one after the other (a frame holds its place on the CU for as long
+        // as this takes).  A lane without a node in block w computes on a zero that nothing reads.
+        bool leaf[VNB];
 #pragma unroll
         for (int w = 0; w < VNB; ++w)
         {
-            my_llr[w] = 0.0;
+            my_llr[w] = 0.0, leaf[w] = false;
             if (w < P.vn_work_stride)
             {
                 const VnBlock b = vn_desc(w);
+                leaf[w] = b.degree == 1; // wave-uniform
                 if (lane < b.count)
-                {
                     my_llr[w] = llr[b.first + lane];
-                    if constexpr (RATIO)
-                    {
-                        if (!(__builtin_fabs(my_llr[w]) <= DM_RATIO_LLR_LIMIT))
-                            escaped = ~0u;
-                        my_llr[w] = dm_exp_clamped(0.0 - my_llr[w]);
-                        if (b.degree == 1) // a leaf keeps its channel ratio rho_ch instead (vn_leaf_ratio)
-                            my_llr[w] = dm_ratio_div(1.0, my_llr[w]);
-                    }
-                }
+            }
+        }
+        if constexpr (RATIO)
+        {
+#pragma unroll
+            for (int w = 0; w < VNB; ++w)
+            {
+                if (!(__builtin_fabs(my_llr[w]) <= DM_RATIO_LLR_LIMIT))
+                    escaped = ~0u;
+                my_llr[w] = dm_exp_clamped(0.0 - my_llr[w]);
+            }
+#pragma unroll
+            for (int w = 0; w < VNB; ++w)
+            {
+                const double rho = dm_ratio_div(1.0, my_llr[w]); // a leaf keeps its channel ratio rho_ch instead (vn_leaf_ratio)
+                my_llr[w] = leaf[w] ? rho : my_llr[w];
             }
         }
         __syncthreads(); // every lane holds its LLRs: the message array may now be written
@@ -1244,7 +1262,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     *slot_ptr<BS>(msg, my_idx[w] & 0xFFFFu) = v0;
                     *slot_ptr<BS>(msg, my_idx[w] >> 16) = v0; // (degree 1: the same slot again)
                 }
-                else if (w == 0 && b.degree >= 3 && b.degree <= 16)
+                else if (w == 0 && b.degree >= 3 && b.degree <= kWideMax)
                 {
                     const double v0 = first_v2c(b, my_llr[w]);
 #pragma unroll
@@ -1380,7 +1398,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                         prod = vn_small_ratio<1, BS>(msg, sl, lam, escaped);
                     else if (b.degree == 2)
                         prod = vn_small_ratio<2, BS>(msg, sl, lam, escaped);
-                    else if (w == 0 && b.degree <= 16)
+                    else if (w == 0 && b.degree <= kWideMax)
                         prod = vn_block_ratio_regs<HANDOVER, BS>(msg, wide_idx, b.degree, lam, escaped);
                     else
                         prod = vn_block_ratio(msg, P.vn_slot + b.idx_off + lane, b.count, b.degree, lam, escaped);
@@ -1505,7 +1523,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                 double out;
                 if (b.degree >= 1 && b.degree <= 2)
                     out = b.degree == 1 ? vn_small_llr<1, BS>(msg, my_idx[w], L) : vn_small_llr<2, BS>(msg, my_idx[w], L);
-                else if (w == 0 && b.degree >= 3 && b.degree <= 16)
+                else if (w == 0 && b.degree >= 3 && b.degree <= kWideMax)
                     out = vn_block_llr_regs<BS>(msg, wide_idx, b.degree, L);
                 else
                     out = vn_block_llr_lean(msg, hb, P.vn_slot + b.idx_off + lane, b.count, b.degree, L, false);

@@ -146,6 +146,7 @@ Plan build_plan(const LdpcCode &code)
         if (static_cast<int>(i) >= p.nct)
             p.rank_kind[p.tx_rank[i]] = 3;
     }
+    p.rank_kind.resize((static_cast<size_t>(p.nc) + 7) / 8 * 8, 0); // (the channel reads the kinds eight at a time)
 
     // ---- LDS footprint of one frame: messages (f64) + input LLRs (f64) + per-slot hard bits ----
     p.lds_bytes = static_cast<size_t>(8) * p.nnz + static_cast<size_t>(8) * p.nc + ((p.nnz + 15) / 16) * 16 + 16;

@@ -604,6 +604,10 @@ void Engine::upload_plan()
     UP(cn_work, p.cn_work);
     UP(cn_work_desc, p.cn_work_desc);
     UP(vn_work_desc, p.vn_work_desc);
+    if (!p.vn_packed.empty())
+        UP(vn_packed, p.vn_packed);
+    else
+        dev_.vn_packed = nullptr;
     dev_.cn_desc_stride = p.cn_desc_stride;
     UP(vn_work, p.vn_work);
     UP(col_rank, p.col_rank);
@@ -758,7 +762,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
             const size_t cu_lds = 160 * 1024, with_llr = plan_.lds_bytes, without = plan_.lds_bytes - 8 * nc;
             int llr_mode = 0;
             if (cu_lds / without > cu_lds / with_llr && plan_.vn_work_stride <= 8 && !plan_.has_isolated_vn &&
-                plan_.nc <= plan_.nnz)
+                plan_.nc <= plan_.nnz && !plan_.vn_packed.empty())
                 llr_mode = 2;
             if (const char *e = std::getenv("LDPC_AMD_LLR_MODE"))
                 llr_mode = std::atoi(e);

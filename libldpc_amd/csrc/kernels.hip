@@ -1090,25 +1090,16 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     constexpr int kSlotShift = BS ? 3 : 0;
     constexpr int kWideMax = BS ? 15 : 16; // widest node whose slot indices the lane keeps in registers (vn_block_ratio_regs)
     auto pick_up_indices = [&] {
+        // as the lane keeps them, from the plan's table (plan.hpp, vn_packed): fifteen loads, none waiting for another (read
+        // off the slot table they were sixteen dependent round trips for the wave that holds the wide block: 7 000 cycles by
+        // which that wave reached the first barrier after the others)
+        const uint32_t *pk = P.vn_packed + (static_cast<uint32_t>(wave) * 16u) * kWaveSize + lane;
 #pragma unroll
         for (int w = 0; w < VNB; ++w)
-            if (w < P.vn_work_stride)
-            {
-                const VnBlock b = vn_desc(w);
-                if (lane < b.count)
-                {
-                    const uint32_t *idx = P.vn_slot + b.idx_off + lane; // LDS-resident: every slot < 2^16
-                    if (b.degree >= 1 && b.degree <= 2)
-                        my_idx[w] = (idx[0] << kSlotShift) | (idx[(b.degree - 1) * b.count] << (16 + kSlotShift));
-                    else if (w == 0 && b.degree <= kWideMax)
-                    {
+            my_idx[w] = pk[w * kWaveSize] << kSlotShift;
 #pragma unroll
-                        for (int q = 0; q < 16; ++q)
-                            if (q < b.degree)
-                                wide_idx[q >> 1] |= idx[q * b.count] << (16 * (q & 1) + kSlotShift);
-                    }
-                }
-            }
+        for (int i = 0; i < 8; ++i)
+            wide_idx[i] = pk[(8 + i) * kWaveSize] << kSlotShift;
     };
     // (the hand-over instantiation picks them up after the channel: fifteen more live registers across the channel code
     // and its allocation falls apart, 36 -> 200 bytes of scratch)
@@ -2176,7 +2167,7 @@ int launch_decode_lds(const DecodeArgs &a, bool min_sum, int max_cn_degree, int 
         return hipSuccess;
     if (llr_mode == kLlrMem && !a.ws_llr)
         return hipErrorInvalidValue;
-    if (llr_mode == kLlrRegs && (a.plan.vn_work_stride > kMaxVnBlocksInRegs || a.plan.nc > a.plan.nnz))
+    if (llr_mode == kLlrRegs && (a.plan.vn_work_stride > kMaxVnBlocksInRegs || a.plan.nc > a.plan.nnz || !a.plan.vn_packed))
         return hipErrorInvalidValue;
     uint32_t lds = a.plan.lds_bytes - (llr_mode != kLlrLds ? 8u * static_cast<uint32_t>(a.plan.nc) : 0u);
     if (a.redo_list) // ratio form: no hard-bit array (the last array of the frame in every layout)

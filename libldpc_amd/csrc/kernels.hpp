@@ -23,6 +23,7 @@ struct DevPlan
     const CnBlock *cn_work_desc; // [kDecodeWaves][cn_desc_stride], count 0 = none
     int cn_desc_stride;
     const uint32_t *vn_work_desc; // [kDecodeWaves][vn_work_stride + 1][4], count 0 = none
+    const uint32_t *vn_packed;    // [kDecodeWaves][16][64] register-held slot indices as the lanes keep them (plan.hpp), or null
     const uint32_t *col_rank;
     const uint32_t *rank_col;
     const uint32_t *tx_rank;

@@ -119,6 +119,28 @@ Plan build_plan(const LdpcCode &code)
                 const VnBlock &vb = p.vn_blocks[b];
                 d[0] = vb.idx_off, d[1] = vb.first, d[2] = vb.count | (static_cast<uint32_t>(vb.degree) << 16);
             }
+    if (p.nnz < 65536 && p.vn_work_stride <= 8)
+    {
+        p.vn_packed.assign(static_cast<size_t>(kDecodeWaves) * 16 * kWaveSize, 0);
+        for (int w = 0; w < kDecodeWaves; ++w)
+            for (int i = 0; i < p.vn_work_stride; ++i)
+            {
+                const uint32_t bi = p.vn_work[static_cast<size_t>(w) * p.vn_work_stride + i];
+                if (bi == 0xFFFF)
+                    continue;
+                const VnBlock &vb = p.vn_blocks[bi];
+                auto slot = [&](int edge, int lane) { return p.vn_slot[vb.idx_off + static_cast<size_t>(edge) * vb.count + lane]; };
+                uint32_t *rows = &p.vn_packed[static_cast<size_t>(w) * 16 * kWaveSize];
+                for (int l = 0; l < vb.count; ++l)
+                {
+                    if (vb.degree >= 1 && vb.degree <= 2)
+                        rows[i * kWaveSize + l] = slot(0, l) | (slot(vb.degree - 1, l) << 16);
+                    else if (i == 0 && vb.degree <= 16)
+                        for (int q = 0; q < vb.degree; ++q)
+                            rows[(8 + q / 2) * kWaveSize + l] |= slot(q, l) << (16 * (q & 1));
+                }
+            }
+    }
     p.cn_desc_stride = (p.cn_work_stride + 1) / 2 * 2 + 2;
     p.cn_work_desc.assign(static_cast<size_t>(kDecodeWaves) * p.cn_desc_stride, CnBlock{0, 0, 0});
     for (int w = 0; w < kDecodeWaves; ++w)

@@ -64,6 +64,12 @@ struct Plan
     std::vector<CnBlock> cn_work_desc; // [kDecodeWaves][cn_desc_stride]
     int cn_desc_stride = 0;
     std::vector<uint32_t> vn_work_desc; // [kDecodeWaves][vn_work_stride + 1][4]: idx_off, first, count | degree << 16, 0
+    // the slot indices a lane of the LDS-resident decoder keeps in registers, as it keeps them (two u16 per word), so that it
+    // picks them up with one load per word, none dependent on another: [kDecodeWaves][16][64] — rows 0..7: block w of the
+    // wave's work list if its nodes have one or two edges (first slot | last slot << 16), rows 8..15: the wave's FIRST block
+    // if its nodes have 3..16 edges (slots 2i, 2i+1 in word i).  Zero where there is nothing.  Empty when a slot needs more
+    // than 16 bits or a wave has more than 8 blocks (such codes do not use the register-held indices).
+    std::vector<uint32_t> vn_packed;
     std::vector<uint32_t> col_rank;  // column -> VN rank
     std::vector<uint32_t> rank_col;  // VN rank -> column
     std::vector<uint32_t> tx_rank;   // transmitted index i -> rank of bit_pos[i]

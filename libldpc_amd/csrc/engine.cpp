@@ -179,7 +179,7 @@ MtDevice::MtDevice()
 {
     // 3360 blocks = 1 048 320 words = 8 MB of raw stream per chunk: the serial twist chain of a chunk hides under the decode
     // kernel and a 65 536-frame batch needs 82 jump-ahead tasks.  LDPC_AMD_CHUNK_BLOCKS: experiments / tests of the chunk edges.
-    chunk_blocks_ = 3360;
+    chunk_blocks_ = 2240;
     if (const char *e = std::getenv("LDPC_AMD_CHUNK_BLOCKS"))
     {
         const long v = std::strtol(e, nullptr, 10);

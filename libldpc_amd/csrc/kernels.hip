@@ -1093,7 +1093,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         // as the lane keeps them, from the plan's table (plan.hpp, vn_packed): fifteen loads, none waiting for another (read
         // off the slot table they were sixteen dependent round trips for the wave that holds the wide block: 7 000 cycles by
         // which that wave reached the first barrier after the others)
-        const uint32_t *pk = P.vn_packed + (static_cast<uint32_t>(wave) * 16u) * kWaveSize + lane;
+        const uint32_t *pk = P.vn_packed + (static_cast<uint32_t>(wave) * kVnPackedRows) * kWaveSize + lane;
 #pragma unroll
         for (int w = 0; w < VNB; ++w)
             my_idx[w] = pk[w * kWaveSize] << kSlotShift;
@@ -1104,25 +1104,48 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     // (the hand-over instantiation picks them up after the channel: fifteen more live registers across the channel code
     // and its allocation falls apart, 36 -> 200 bytes of scratch)
     constexpr bool kIndicesInRegs = LLR_MODE == kLlrRegs && (RATIO || MINSUM);
-    if constexpr (kIndicesInRegs && !HANDOVER)
-        pick_up_indices();
+    // kLaneChannel: every lane computes the input LLRs of its own variable nodes straight from the channel's data
+    // (device_channel.hpp, channel_lanes): nothing is staged in LDS, no barrier stands between the channel and the first
+    // variable-node work, and a frame's prologue is one round trip to the normals instead of a chain of them
+    constexpr bool kLaneChannel = kIndicesInRegs && !HANDOVER;
+    double my_llr[VNB + 1]; // (my_llr, my_idx: one constant entry of padding — the lock-step loops below name block w + 1, which an odd VNB does not have)
+    my_llr[VNB] = 0.0;
 
     // ---- channel + LLR initialisation (device_channel.hpp) ----
-    channel_init<kThreads>(a, frame, llr, tid);
+    if constexpr (kLaneChannel)
+    {
+        const uint32_t *lane_pk = P.vn_packed + (static_cast<uint32_t>(wave) * kVnPackedRows) * kWaveSize + lane;
+        channel_lanes<VNB>(a, frame, lane_pk, my_llr);
+        // the slot indices now: their loads fly while the LLRs below become lambda (issued before the channel's loads they
+        // would sit in fifteen registers across them, which the kernels at 96 do not have)
+        pick_up_indices();
+        if (a.llr_in_dump)
+        {
+            double *o = a.llr_in_dump + frame * nc;
+#pragma unroll
+            for (int w = 0; w < VNB; ++w)
+                if (const uint32_t col = lane_pk[(24 + w) * kWaveSize]; col != kVnSrcZero)
+                    o[col] = my_llr[w];
+        }
+    }
+    else
+        channel_init<kThreads>(a, frame, llr, tid);
 #ifdef LDPC_AMD_PHASE_TRACE
     const uint64_t tr_chan0 = __builtin_amdgcn_s_memtime();
 #endif
-    __syncthreads();
+    if constexpr (!kLaneChannel)
+        __syncthreads();
 #ifdef LDPC_AMD_PHASE_TRACE
     const uint64_t tr_chan = __builtin_amdgcn_s_memtime();
 #endif
 
-    if (a.llr_in_dump)
-    {
-        double *o = a.llr_in_dump + frame * nc;
-        for (int r = tid; r < nc; r += kThreads)
-            o[P.rank_col[r]] = llr[r];
-    }
+    if constexpr (!kLaneChannel)
+        if (a.llr_in_dump)
+        {
+            double *o = a.llr_in_dump + frame * nc;
+            for (int r = tid; r < nc; r += kThreads)
+                o[P.rank_col[r]] = llr[r];
+        }
 
     uint32_t escaped = 0; // RATIO: running maximum of dm_ratio_key over the frame's checked values (detmath.h)
     [[maybe_unused]] int32_t ho_key = 0; // HANDOVER: running maximum of dm_handover_key over the variable-node totals
@@ -1141,8 +1164,6 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     }
     if constexpr (kIndicesInRegs && HANDOVER)
         pick_up_indices();
-    double my_llr[VNB + 1]; // (my_llr, my_idx: one constant entry of padding — the lock-step loops below name block w + 1, which an odd VNB does not have)
-    my_llr[VNB] = 0.0;
     if constexpr (LLR_MODE == kLlrRegs)
     {
         // every block's LLR first, then every block's arithmetic, branch-free: seven exponentials in lock step instead of
@@ -1152,13 +1173,16 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 #pragma unroll
         for (int w = 0; w < VNB; ++w)
         {
-            my_llr[w] = 0.0, leaf[w] = false;
+            leaf[w] = false;
+            if constexpr (!kLaneChannel)
+                my_llr[w] = 0.0;
             if (w < P.vn_work_stride)
             {
                 const VnBlock b = vn_desc(w);
                 leaf[w] = b.degree == 1; // wave-uniform
-                if (lane < b.count)
-                    my_llr[w] = llr[b.first + lane];
+                if constexpr (!kLaneChannel)
+                    if (lane < b.count)
+                        my_llr[w] = llr[b.first + lane];
             }
         }
         if constexpr (RATIO)
@@ -1177,7 +1201,8 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                 my_llr[w] = leaf[w] ? rho : my_llr[w];
             }
         }
-        __syncthreads(); // every lane holds its LLRs: the message array may now be written
+        if constexpr (!kLaneChannel)
+            __syncthreads(); // every lane holds its LLRs: the message array may now be written
     }
     // (the check-node work list likewise: cn_work_desc)
     const auto my_cdesc = uniform_table(reinterpret_cast<const uint32_t *>(P.cn_work_desc + wave * P.cn_desc_stride));

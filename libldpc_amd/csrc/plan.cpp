@@ -119,28 +119,6 @@ Plan build_plan(const LdpcCode &code)
                 const VnBlock &vb = p.vn_blocks[b];
                 d[0] = vb.idx_off, d[1] = vb.first, d[2] = vb.count | (static_cast<uint32_t>(vb.degree) << 16);
             }
-    if (p.nnz < 65536 && p.vn_work_stride <= 8)
-    {
-        p.vn_packed.assign(static_cast<size_t>(kDecodeWaves) * 16 * kWaveSize, 0);
-        for (int w = 0; w < kDecodeWaves; ++w)
-            for (int i = 0; i < p.vn_work_stride; ++i)
-            {
-                const uint32_t bi = p.vn_work[static_cast<size_t>(w) * p.vn_work_stride + i];
-                if (bi == 0xFFFF)
-                    continue;
-                const VnBlock &vb = p.vn_blocks[bi];
-                auto slot = [&](int edge, int lane) { return p.vn_slot[vb.idx_off + static_cast<size_t>(edge) * vb.count + lane]; };
-                uint32_t *rows = &p.vn_packed[static_cast<size_t>(w) * 16 * kWaveSize];
-                for (int l = 0; l < vb.count; ++l)
-                {
-                    if (vb.degree >= 1 && vb.degree <= 2)
-                        rows[i * kWaveSize + l] = slot(0, l) | (slot(vb.degree - 1, l) << 16);
-                    else if (i == 0 && vb.degree <= 16)
-                        for (int q = 0; q < vb.degree; ++q)
-                            rows[(8 + q / 2) * kWaveSize + l] |= slot(q, l) << (16 * (q & 1));
-                }
-            }
-    }
     p.cn_desc_stride = (p.cn_work_stride + 1) / 2 * 2 + 2;
     p.cn_work_desc.assign(static_cast<size_t>(kDecodeWaves) * p.cn_desc_stride, CnBlock{0, 0, 0});
     for (int w = 0; w < kDecodeWaves; ++w)
@@ -169,6 +147,40 @@ Plan build_plan(const LdpcCode &code)
             p.rank_kind[p.tx_rank[i]] = 3;
     }
     p.rank_kind.resize((static_cast<size_t>(p.nc) + 7) / 8 * 8, 0); // (the channel reads the kinds eight at a time)
+
+    // ---- what a lane of the LDS-resident decoder keeps in registers, as it keeps it (plan.hpp, vn_packed) ----
+    if (p.nnz < 65536 && p.vn_work_stride <= 8)
+    {
+        p.vn_packed.assign(static_cast<size_t>(kDecodeWaves) * kVnPackedRows * kWaveSize, 0);
+        std::vector<uint32_t> rank_tx(p.nc, kVnSrcZero); // rank -> index among the transmitted bits
+        for (int i = 0; i < p.nct; ++i)
+            rank_tx[p.tx_rank[i]] = static_cast<uint32_t>(i);
+        for (int w = 0; w < kDecodeWaves; ++w)
+        {
+            uint32_t *rows = &p.vn_packed[static_cast<size_t>(w) * kVnPackedRows * kWaveSize];
+            std::fill(rows + 16 * kWaveSize, rows + 32 * kWaveSize, kVnSrcZero);
+            for (int i = 0; i < p.vn_work_stride; ++i)
+            {
+                const uint32_t bi = p.vn_work[static_cast<size_t>(w) * p.vn_work_stride + i];
+                if (bi == 0xFFFF)
+                    continue;
+                const VnBlock &vb = p.vn_blocks[bi];
+                auto slot = [&](int edge, int lane) { return p.vn_slot[vb.idx_off + static_cast<size_t>(edge) * vb.count + lane]; };
+                for (int l = 0; l < vb.count; ++l)
+                {
+                    if (vb.degree >= 1 && vb.degree <= 2)
+                        rows[i * kWaveSize + l] = slot(0, l) | (slot(vb.degree - 1, l) << 16);
+                    else if (i == 0 && vb.degree <= 16)
+                        for (int q = 0; q < vb.degree; ++q)
+                            rows[(8 + q / 2) * kWaveSize + l] |= slot(q, l) << (16 * (q & 1));
+                    const uint32_t r = vb.first + l;
+                    const uint8_t kind = p.rank_kind[r];
+                    rows[(16 + i) * kWaveSize + l] = kind == 2 ? kVnSrcShortened : (kind == 0 ? rank_tx[r] : kVnSrcZero);
+                    rows[(24 + i) * kWaveSize + l] = p.rank_col[r];
+                }
+            }
+        }
+    }
 
     // ---- LDS footprint of one frame: messages (f64) + input LLRs (f64) + per-slot hard bits ----
     p.lds_bytes = static_cast<size_t>(8) * p.nnz + static_cast<size_t>(8) * p.nc + ((p.nnz + 15) / 16) * 16 + 16;

@@ -38,6 +38,9 @@ struct CnBlock
     uint16_t degree;
 };
 
+constexpr int kVnPackedRows = 32;
+constexpr uint32_t kVnSrcZero = 0xFFFFFFFFu, kVnSrcShortened = 0xFFFFFFFEu;
+
 struct VnBlock
 {
     uint32_t idx_off; // into vn_slot: [idx_off + p*count + lane]
@@ -65,10 +68,13 @@ struct Plan
     int cn_desc_stride = 0;
     std::vector<uint32_t> vn_work_desc; // [kDecodeWaves][vn_work_stride + 1][4]: idx_off, first, count | degree << 16, 0
     // the slot indices a lane of the LDS-resident decoder keeps in registers, as it keeps them (two u16 per word), so that it
-    // picks them up with one load per word, none dependent on another: [kDecodeWaves][16][64] — rows 0..7: block w of the
-    // wave's work list if its nodes have one or two edges (first slot | last slot << 16), rows 8..15: the wave's FIRST block
-    // if its nodes have 3..16 edges (slots 2i, 2i+1 in word i).  Zero where there is nothing.  Empty when a slot needs more
-    // than 16 bits or a wave has more than 8 blocks (such codes do not use the register-held indices).
+    // picks them up with one load per word, none dependent on another: [kDecodeWaves][kVnPackedRows][64] — rows 0..7: block
+    // w of the wave's work list if its nodes have one or two edges (first slot | last slot << 16), rows 8..15: the wave's
+    // FIRST block if its nodes have 3..16 edges (slots 2i, 2i+1 in word i); zero where there is nothing.  Rows 16..23: where
+    // the LLR of the lane's node in block w comes from — the index of its bit among the transmitted ones, or kVnSrcZero
+    // (punctured, never written by the channel, no node) / kVnSrcShortened; rows 24..31: the node's column (kVnSrcZero: no
+    // node).  Empty when a slot needs more than 16 bits or a wave has more than 8 blocks (such codes do not use the
+    // register-held indices).
     std::vector<uint32_t> vn_packed;
     std::vector<uint32_t> col_rank;  // column -> VN rank
     std::vector<uint32_t> rank_col;  // VN rank -> column

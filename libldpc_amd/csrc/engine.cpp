@@ -177,8 +177,9 @@ void *DeviceBuffer::reserve(size_t bytes)
 // ---------------------------------------------------------------------------------------------
 MtDevice::MtDevice()
 {
-    // 3360 blocks = 1 048 320 words = 8 MB of raw stream per chunk: the serial twist chain of a chunk hides under the decode
-    // kernel and a 65 536-frame batch needs 82 jump-ahead tasks.  LDPC_AMD_CHUNK_BLOCKS: experiments / tests of the chunk edges.
+    // 2240 blocks = 698 880 words = 5.6 MB of raw stream per chunk: the serial twist chain of a chunk hides under the decode
+    // kernel (whose waves outrank it: at 3360 blocks the chain had become as long as the headline kernel) and a 65 536-frame
+    // batch needs 123 jump-ahead tasks, issued two steps ahead.  LDPC_AMD_CHUNK_BLOCKS: experiments / tests of the chunk edges.
     chunk_blocks_ = 2240;
     if (const char *e = std::getenv("LDPC_AMD_CHUNK_BLOCKS"))
     {

@@ -56,7 +56,7 @@ __device__ __forceinline__ void mt_regenerate(uint64_t *x, int lane)
 // Three waves per chunk, kGenChunks chunks per workgroup.  The twist has 156-way parallelism: words 0..155 of the next
 // window depend only on the current window, words 156..311 on the current window and the new words 0..155.
 // Thread t < 156 of a chunk's three waves produces words t and t+156; reads and writes of a half are separated by
-// workgroup barriers.  Several chunks share a workgroup so that a batch's 82 chunks occupy 21 compute units for the
+// workgroup barriers.  Several chunks share a workgroup so that a batch's 123 chunks occupy 31 compute units for the
 // length of the serial chain and not 82: the register-resident decode kernel owns a whole CU per frame, and every CU
 // that hosts a generator wave is lost to it for that long.
 // (kGenChunks = 1 when the decode kernel shares its CUs anyway: packed chunks lengthen the serial chain, which then

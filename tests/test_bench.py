@@ -106,7 +106,7 @@ def test_bench_two_ranks_rehearsal():
     B, K, W = 4096, 2, 1
     j = last_json(run_bench("--gpus", "2", "--steps", str(K), "--warmup", str(W), "--batch", str(B), "--no-cpu-baseline", "--no-pmc",
                             env={"LDPC_BENCH_ONE_GPU": "1", "LDPC_BENCH_BACKEND": "gloo"}))
-    # (a rank's piece is a whole number of 8 MB generator chunks, about 804 frames of this code each: 5 chunks here)
+    # (a rank's piece is a whole number of 5.6 MB generator chunks, about 536 frames of this code each)
     assert j["n_gpus"] == 2 and abs(j["config"]["frames_per_step"] - 2 * B) < 0.15 * B
     first, end = j["timed_frame_span"]
     assert first >= W * 2 * B * 0.85 and end - first == j["counters"]["frames"]

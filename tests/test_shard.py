@@ -90,7 +90,7 @@ def test_sharded_frames_keep_their_results(case, world):
             nxt += step[3]
         assert nxt == step0[0] + step0[1]
         pos = nxt
-    assert total >= target * steps * 0.8  # (a rank's piece is a whole number of generator chunks: about 804 frames of this code each)
+    assert total >= target * steps * 0.8  # (a rank's piece is a whole number of generator chunks: about 536 frames of this code each)
 
 
 @pytest.mark.gpu

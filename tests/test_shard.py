@@ -90,7 +90,7 @@ def test_sharded_frames_keep_their_results(case, world):
             nxt += step[3]
         assert nxt == step0[0] + step0[1]
         pos = nxt
-    assert total >= target * steps * 0.8  # (a rank's piece is a whole number of generator chunks: about 536 frames of this code each)
+    assert total >= target * steps * 0.7  # (a rank's piece is a whole number of generator chunks: about 536 frames of this code each)
 
 
 @pytest.mark.gpu
@@ -126,7 +126,7 @@ def test_sharded_frames_keep_their_results_config4_code(case, world, h8k_file):
             nxt += step[3]
         assert nxt == step0[0] + step0[1]
         pos = nxt
-    assert total >= target * steps * 0.8
+    assert total >= target * steps * 0.7
 
 
 def test_sharded_step_failure_reaches_every_rank():

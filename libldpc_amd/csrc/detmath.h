@@ -575,6 +575,122 @@ DM_FN uint32_t dm_cn4_shared(double *v)
     return h01 > h23 ? h01 : h23;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused form (round 4): the first of the three launches of sum-product WITH early termination, for codes whose check
+ * nodes have 2..4 edges and at most one degree-1 neighbour each (fused_rule.h: a property of the code alone; the n = 1024
+ * test code is such a code).  Same iteration as the likelihood-ratio form above, with three changes that take work out of
+ * it.  Every quantity stays positive, nothing cancels; the det-mode oracle runs the same functions.
+ *
+ * 1. Order of a check node's inputs.  The node takes its neighbours of degree >= 3 first, then those of degree 2, then its
+ *    degree-1 neighbour (a LEAF), each group in row file order.  The box-plus is associative and commutative, so the
+ *    forward/backward recursion of decoder.cpp:31-44 over this order yields the same messages up to rounding.
+ * 2. A leaf never changes its v2c message: out - c2v = L_ch (decoder.cpp:50-64), i.e. rho_ch.  All the node's other
+ *    outputs need from it is that constant, and all the decoder needs from the message c2v = n / d the node would send to
+ *    it is the hard decision  out <= 0  <=>  lambda(c2v) >= rho_ch  <=>  n >= rho_ch d  (d > 0): one multiplication and a
+ *    comparison instead of a division, a message slot and a variable-node visit.  The check node keeps the decision.
+ * 3. A variable node of degree 2 divides only to undo its own inputs: rho(v2c_0) = rho_ch rho(c2v_1).  The check node hands
+ *    such a neighbour rho(c2v) = d / n instead of lambda(c2v) = n / d — the same reciprocal sequence with numerator and
+ *    denominator exchanged ("flipped" output) — and the variable node multiplies: no division at all.  Its decision is
+ *    rho(total) = rho_ch rho(c2v_0) rho(c2v_1) <= 1.
+ *
+ * Reciprocals are shared as in the shared-reciprocal form: a node of degree 3 inverts the product of the (two or three)
+ * denominators of its message outputs, a node of degree 4 those of outputs 0,1 and of outputs 2,3 (a leaf's partner is
+ * divided on its own).  Every product inverted — a single denominator counts — must stay below 2^897 (DM_FUSED_P_HI on its
+ * upper word; infinities, NaNs and negative patterns compare above it): a frame in which one does not is decoded again by
+ * the separately divided ratio form, exactly like a frame that left the box.  With inputs inside [2^-240, 2^240) no product
+ * falls below 2^-720.  Functions: v[] = rho(v2c) of the node's inputs in the order of item 1 (a leaf's entry = rho_ch) on
+ * entry; on return v[k] = the message for neighbour k — lambda(c2v_k), or rho(c2v_k) where bit k of `flip` is set; the
+ * leaf's entry is left alone.  *leaf_bit = its hard decision; *leaf_tot (may be null) = lambda(total) of the leaf, for the
+ * LLR output.  Returns the largest upper word among the products inverted.
+ * ------------------------------------------------------------------------------------------------ */
+#define DM_FUSED_P_HI 0x78000000u /* upper word of 2^897 */
+DM_FN uint32_t dm_hi(double x) { return (uint32_t)(dm_bits(x) >> 32); }
+DM_FN uint32_t dm_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+DM_FN uint32_t dm_cnf2(double *v, unsigned flip)
+{
+    const double a = v[0], b = v[1];
+    uint32_t h = 0;
+    if (flip & 1u)
+        v[0] = b; /* rho(c2v_0) = rho(v2c_1) */
+    else
+        v[0] = dm_ratio_div(1.0, b), h = dm_hi(b);
+    if (flip & 2u)
+        v[1] = a;
+    else
+        v[1] = dm_ratio_div(1.0, a), h = dm_umax(h, dm_hi(a));
+    return h;
+}
+
+DM_FN uint32_t dm_cnf3(double *v, unsigned flip, int leaf, uint32_t *leaf_bit, double *leaf_tot)
+{
+    const double n0 = v[2] + v[1], d0 = DM_FMA(v[2], v[1], 1.0); /* B[1] = B[2] [+] v[1] */
+    const double n1 = v[0] + v[2], d1 = DM_FMA(v[0], v[2], 1.0); /* F[0] [+] B[2] */
+    const double n2 = v[0] + v[1], d2 = DM_FMA(v[0], v[1], 1.0); /* F[1] = F[0] [+] v[1] */
+    const double N0 = (flip & 1u) ? d0 : n0, D0 = (flip & 1u) ? n0 : d0;
+    const double N1 = (flip & 2u) ? d1 : n1, D1 = (flip & 2u) ? n1 : d1;
+    if (leaf) /* v[2] = rho_ch of the leaf */
+    {
+        const double P = D0 * D1;
+        const double r = dm_ratio_div(1.0, P);
+        const double i0 = r * D1, i1 = r * D0;
+        const double t = v[2] * d2;
+        v[0] = N0 * i0, v[1] = N1 * i1;
+        *leaf_bit = n2 >= t;
+        if (leaf_tot)
+            *leaf_tot = dm_ratio_div(n2, t);
+        return dm_hi(P);
+    }
+    const double N2 = (flip & 4u) ? d2 : n2, D2 = (flip & 4u) ? n2 : d2;
+    const double p01 = D0 * D1, P = p01 * D2;
+    const double r = dm_ratio_div(1.0, P);
+    const double i2 = r * p01, t = r * D2;
+    const double i0 = t * D1, i1 = t * D0;
+    v[0] = N0 * i0, v[1] = N1 * i1, v[2] = N2 * i2;
+    return dm_hi(P);
+}
+
+DM_FN uint32_t dm_cnf4(double *v, unsigned flip, int leaf, uint32_t *leaf_bit, double *leaf_tot)
+{
+    const double nF = DM_FMA(v[0], v[1], 1.0), dF = v[0] + v[1]; /* F[1] = nF / dF */
+    const double nB = DM_FMA(v[3], v[2], 1.0), dB = v[3] + v[2]; /* B[2] = nB / dB */
+    const double n0 = DM_FMA(dB, v[1], nB), d0 = DM_FMA(nB, v[1], dB); /* B[1] = B[2] [+] v[1] */
+    const double n1 = DM_FMA(dB, v[0], nB), d1 = DM_FMA(nB, v[0], dB); /* F[0] [+] B[2] */
+    const double N0 = (flip & 1u) ? d0 : n0, D0 = (flip & 1u) ? n0 : d0;
+    const double N1 = (flip & 2u) ? d1 : n1, D1 = (flip & 2u) ? n1 : d1;
+    const double p01 = D0 * D1;
+    const double r01 = dm_ratio_div(1.0, p01);
+    const double o0 = N0 * (r01 * D1), o1 = N1 * (r01 * D0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0); /* the two halves one after the other: registers (dm_cn4_shared) */
+#endif
+    const double n2 = DM_FMA(dF, v[3], nF), d2 = DM_FMA(nF, v[3], dF); /* F[1] [+] B[3] */
+    const double n3 = DM_FMA(dF, v[2], nF), d3 = DM_FMA(nF, v[2], dF); /* F[2] = F[1] [+] v[2] */
+    const double N2 = (flip & 4u) ? d2 : n2, D2 = (flip & 4u) ? n2 : d2;
+    if (leaf) /* v[3] = rho_ch of the leaf */
+    {
+        const double o2 = dm_ratio_div(N2, D2);
+        const double t = v[3] * d3;
+        v[0] = o0, v[1] = o1, v[2] = o2;
+        *leaf_bit = n3 >= t;
+        if (leaf_tot)
+            *leaf_tot = dm_ratio_div(n3, t);
+        return dm_umax(dm_hi(p01), dm_hi(D2));
+    }
+    const double N3 = (flip & 8u) ? d3 : n3, D3 = (flip & 8u) ? n3 : d3;
+    const double p23 = D2 * D3;
+    const double r23 = dm_ratio_div(1.0, p23);
+    v[0] = o0, v[1] = o1, v[2] = N2 * (r23 * D3), v[3] = N3 * (r23 * D2);
+    return dm_umax(dm_hi(p01), dm_hi(p23));
+}
+
+/* the box [2^-240, 2^240) on the upper word of a positive double (what DM_RATIO_TRACK checks, as two running extremes:
+   one v_max3 / v_min3 pair per two values on the device); zero, denormals, negative patterns, infinities and NaNs fall
+   outside */
+#define DM_BOX_HI_WORD ((1023u + 240u) << 20)
+#define DM_BOX_LO_WORD ((1023u - 240u) << 20)
+DM_FN int dm_box_escaped(uint32_t hi_max, uint32_t hi_min) { return hi_max >= DM_BOX_HI_WORD || hi_min < DM_BOX_LO_WORD; }
+
 /*
  * Hand-over (sum-product WITHOUT early termination).  With the syndrome check off a frame keeps iterating after it has
  * converged and its LLRs grow until they leave the box the ratio form can hold; decoding such frames in the LLR domain

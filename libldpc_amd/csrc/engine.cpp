@@ -453,6 +453,8 @@ Engine::Engine(const std::string &pc_file, const std::string &gen_file, int devi
     if (code_->min_cn_degree() < 2)
         throw std::runtime_error("check nodes of degree < 2 are not supported (undefined in the reference decoder)");
     plan_ = build_plan(*code_);
+    if (plan_.lds_ok && !std::getenv("LDPC_AMD_NO_FUSED")) // (the variable: experiments only — results change by ulps)
+        fused_plan_ = build_fused_plan(*code_, plan_);
     if (!plan_.lds_ok) // register-resident decoder: the smallest register tile the code fits
     {
         // One frame per CU (1024 threads, 128 VGPRs, 160 KB mailbox) first: measured 1.37x faster on the n=8192
@@ -642,6 +644,19 @@ void Engine::upload_plan()
         dev_reg2_.vn_blocks = static_cast<const Reg2VnBlock *>(up(r.vn_blocks.data(), r.vn_blocks.size() * sizeof(Reg2VnBlock)));
         dev_reg2_.vn_rank = static_cast<const uint32_t *>(up(r.vn_rank.data(), r.vn_rank.size() * 4));
     }
+    if (fused_plan_.ok)
+    {
+        const FusedPlan &f = fused_plan_;
+        dev_fused_.n_slots = f.n_slots, dev_fused_.vnb = f.vnb, dev_fused_.cnl = f.cnl, dev_fused_.calls_stride = f.calls_stride;
+        dev_fused_.has_shortened = f.has_shortened ? 1 : 0;
+        // the message slots; the prologue stages one 16-byte entry per transmitted bit or column (+ 2) in the same space
+        dev_fused_.lds_bytes = static_cast<uint32_t>(std::max<size_t>(8 * static_cast<size_t>(f.n_slots), 16 * (static_cast<size_t>(std::max(p.nc, p.nct)) + 2)) + 15) & ~15u;
+        dev_fused_.leaf_calls = static_cast<const FusedCall *>(up(f.leaf_calls.data(), f.leaf_calls.size() * sizeof(FusedCall)));
+        dev_fused_.calls = static_cast<const FusedCall *>(up(f.calls.data(), f.calls.size() * sizeof(FusedCall)));
+        dev_fused_.vn_desc = static_cast<const uint32_t *>(up(f.vn_desc.data(), f.vn_desc.size() * 4));
+        dev_fused_.vn_slot = static_cast<const uint32_t *>(up(f.vn_slot.data(), f.vn_slot.size() * 4));
+        dev_fused_.lane_tab = static_cast<const uint32_t *>(up(f.lane_tab.data(), f.lane_tab.size() * 4));
+    }
     if (code_->has_G())
     {
         std::vector<uint32_t> cp(code_->G.cptr.begin(), code_->G.cptr.end()), cr(code_->G.crow.begin(), code_->G.crow.end());
@@ -755,7 +770,10 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         return;
     }
     const auto launch = [&] {
-        if (plan_.lds_ok)
+        // the first launch of sum-product with early termination, for codes the fused form takes (fused_rule.h)
+        if (fused_plan_.ok && !p.min_sum && p.early_term && a.redo_list && !a.redo_count_in && !a.ratio_separate)
+            check(launch_decode_fused(a, dev_fused_, s), "decode (fused form)");
+        else if (plan_.lds_ok)
         {
             // Input LLRs: in registers when that frees the LDS for one more resident frame per CU (n=1024 code:
             // 40 KB -> 31 KB, five frames instead of four) and the plan allows it; in LDS otherwise.  Device memory

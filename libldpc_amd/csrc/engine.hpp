@@ -166,6 +166,7 @@ class Engine
     const Plan &plan() const { return plan_; }
     const RegPlan &reg_plan() const { return reg_plan_; }
     const Reg2Plan &reg2_plan() const { return reg2_plan_; }
+    const FusedPlan &fused_plan() const { return fused_plan_; }
     int device() const { return device_; }
     bool bec_deg1_compat = false;
     // opt-in NON-PARITY modes, off (0) by default and never chosen by the library: 1 = flooding sum-product with binary32
@@ -249,6 +250,8 @@ class Engine
     Plan plan_;
     RegPlan reg_plan_;
     Reg2Plan reg2_plan_;
+    FusedPlan fused_plan_; // fused form of the first ratio launch (kernels_fused.hip); ok = the code qualifies (fused_rule.h)
+    DevFusedPlan dev_fused_{};
     LayerPlan layer_plan_;
     DevLayerPlan dev_layer_{};
     DevPlan dev_{};

@@ -127,6 +127,21 @@ struct DevReg2Plan
     const uint32_t *vn_rank;
 };
 
+// device copy of FusedPlan (fused form of the likelihood-ratio iteration: kernels_fused.hip)
+struct DevFusedPlan
+{
+    int n_slots, vnb, cnl, calls_stride;
+    int has_shortened;
+    uint32_t lds_bytes;          // dynamic LDS per frame: the message slots, or the staging area of the prologue if larger
+    const FusedCall *leaf_calls; // [kDecodeWaves][kFusedLeafCalls]
+    const FusedCall *calls;      // [kDecodeWaves][calls_stride]
+    const uint32_t *vn_desc;     // [kDecodeWaves][kFusedVnSlots][4]
+    const uint32_t *vn_slot;
+    const uint32_t *lane_tab;    // [kDecodeWaves][kFusedLaneRows][64]
+};
+// first launch of sum-product with early termination (a.redo_list / a.redo_count set, a.early_term, no a.redo_count_in)
+int launch_decode_fused(const DecodeArgs &a, const DevFusedPlan &f, void *stream);
+
 // BEC (u8 erasure alphabet, decoder.cpp:91-192 + channel.cpp:199-229)
 struct BecArgs
 {

@@ -1,0 +1,718 @@
+// kernels_fused.hip — the fused form of the likelihood-ratio iteration (detmath.h "Fused form", fused_rule.h, plan.hpp
+// FusedPlan): first launch of sum-product with early termination for codes whose check nodes have 2..4 edges and at most
+// one leaf each — the n = 1024 test code of the reference and the headline workload.  One workgroup (4 waves) per frame,
+// messages in LDS, hand-written for gfx950 / wave64.
+//
+// Reference semantics restated (file:line in heat1q/libldpc): decode loop src/decoding/decoder.cpp:11-78, box-plus
+// src/decoding/decoder.h:12-15, syndrome early termination decoder.h:47-64, channel + LLRs src/sim/channel.cpp:62-93 /
+// 129-162, bit-error count src/sim/ldpcsim.cpp:184-188.
+//
+// What differs from the general LDS-resident kernel (kernels.hip, decode_body<RATIO>):
+//   * prologue: the frame's channel values are evaluated ONCE, spread evenly over the 256 threads — transmitted bit i by
+//     thread i mod 256: LLR, lambda = e^-L, rho = 1 / lambda — and staged in the (still unused) message area, from where
+//     every lane picks up the values of the nodes it serves.  (The general kernel lets every lane evaluate the seven block
+//     slots of its wave whether they hold a node or not, with 64-bit slab arithmetic per value: 260 k lane-instructions per
+//     frame of the n = 1024 code, a fifth of the kernel.  Here the slab addressing is wave-uniform scalar work.)
+//   * a leaf (degree-1 variable node) has no message slot and no variable-node visit: its check node's lane keeps its
+//     channel ratio in a register and takes its hard decision by one multiplication and a comparison;
+//   * a variable node of degree 2 multiplies (its check nodes hand it rho(c2v)): no division;
+//   * hard decisions live in registers of the lanes that make them (one bit per block slot), so check-node outputs carry
+//     no sign and the epilogue reads no message;
+//   * the box check of the v2c messages is a running max3 / min3 over their upper words.
+// Frames whose values leave the box (or whose denominator products leave theirs) go to a.redo_list, as in the general
+// kernel; the second launch (separately divided ratio form, kernels.hip) decodes them from scratch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "device_math.hpp"
+#include "fused_rule.h"
+#include "kernels.hpp"
+
+#ifndef LDPC_AMD_DECODE_PRIO
+#define LDPC_AMD_DECODE_PRIO 3
+#endif
+#ifndef LDPC_AMD_FUSED_WAVES
+#define LDPC_AMD_FUSED_WAVES 4
+#endif
+
+namespace ldpc_amd
+{
+
+namespace
+{
+
+constexpr int kThreads = kDecodeWaves * kWaveSize;
+
+__device__ __forceinline__ uint32_t hi_word(double x) { return static_cast<uint32_t>(dm_bits(x) >> 32); }
+__device__ __forceinline__ double with_sign(double mag, uint32_t sign_hi) // mag > 0, sign_hi = 0 or 0x80000000
+{
+    return dm_from_bits(dm_bits(mag) | (static_cast<uint64_t>(sign_hi) << 32));
+}
+__device__ __forceinline__ double *at(char *msg, uint32_t byte_off) { return reinterpret_cast<double *>(msg + byte_off); }
+
+// running extremes of the upper words of the v2c messages (detmath.h, dm_box_escaped) and of the inverted products
+struct Track
+{
+    uint32_t hmax, hmin, pmax;
+};
+__device__ __forceinline__ void track(Track &t, double a)
+{
+    t.hmax = max(t.hmax, hi_word(a));
+    t.hmin = min(t.hmin, hi_word(a));
+}
+__device__ __forceinline__ void track2(Track &t, double a, double b)
+{
+    t.hmax = max(max(t.hmax, hi_word(a)), hi_word(b)); // v_max3_u32
+    t.hmin = min(min(t.hmin, hi_word(a)), hi_word(b)); // v_min3_u32
+}
+
+// ---- check nodes ------------------------------------------------------------------------------------------------------
+// One call = one or two blocks (TWO: both full, 64 nodes) of one class <D, LEAF, FLIP>: M = D - LEAF message inputs per node
+// at p + k * stride, the leaf's channel ratio in rho*.  prev* (bit 31): the leaf's decision of the previous pass, which
+// joins the parity of the node; lb*: its new decision.  Returns the parity words (bit 31 counts) of the nodes, or-ed.
+template <int D, bool LEAF, unsigned FLIP, bool TWO, bool WANT_TOT>
+__device__ __forceinline__ uint32_t cnf_call(char *msg, uint32_t off0, uint32_t off1, uint32_t cnt0, int lane, double rho0, double rho1,
+                                             uint32_t prev0, uint32_t prev1, uint32_t &lb0, uint32_t &lb1, Track &t, double &tot0,
+                                             double &tot1)
+{
+    constexpr int M = D - (LEAF ? 1 : 0);
+    const uint32_t stride = TWO ? kWaveSize * 8u : cnt0 * 8u;
+    char *p0 = msg + off0 + lane * 8, *p1 = msg + off1 + lane * 8;
+    double v0[D], v1[D];
+    uint32_t par0 = prev0, par1 = prev1;
+#pragma unroll
+    for (int k = 0; k < M; ++k)
+    {
+        const double x = *at(p0, k * stride);
+        par0 ^= hi_word(x);
+        v0[k] = __builtin_fabs(x);
+    }
+    if constexpr (TWO)
+    {
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+        {
+            const double x = *at(p1, k * stride);
+            par1 ^= hi_word(x);
+            v1[k] = __builtin_fabs(x);
+        }
+    }
+    if constexpr (LEAF)
+        v0[M] = rho0, v1[M] = rho1;
+    auto node = [&](double(&v)[D], uint32_t &lb, double &tot) {
+        uint32_t h;
+        if constexpr (D == 2)
+            h = dm_cnf2(v, FLIP);
+        else if constexpr (D == 3)
+            h = dm_cnf3(v, FLIP, LEAF, &lb, WANT_TOT ? &tot : nullptr);
+        else
+            h = dm_cnf4(v, FLIP, LEAF, &lb, WANT_TOT ? &tot : nullptr);
+        t.pmax = max(t.pmax, h);
+    };
+    node(v0, lb0, tot0);
+    if constexpr (TWO)
+        node(v1, lb1, tot1);
+#pragma unroll
+    for (int k = 0; k < M; ++k)
+        *at(p0, k * stride) = v0[k];
+    if constexpr (TWO)
+    {
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+            *at(p1, k * stride) = v1[k];
+        return par0 | par1;
+    }
+    return par0;
+}
+
+// class keys (fused_rule.h, dm_fused_class): the flipped outputs are the last NM of the node's M message inputs
+constexpr unsigned cls_key(int d, int leaf, int nm) { return static_cast<unsigned>(d) | (static_cast<unsigned>(leaf) << 3) | ((((1u << nm) - 1u) << (d - leaf - nm)) << 4); }
+constexpr unsigned cls_flip(int d, int leaf, int nm) { return ((1u << nm) - 1u) << (d - leaf - nm); }
+
+// ---- variable nodes ---------------------------------------------------------------------------------------------------
+// degree 2, two nodes of two full blocks in lock step (detmath.h "Fused form", item 3): inputs rho(c2v), outputs
+// rho(v2c_0) = rho_ch rho(c2v_1), rho(v2c_1) = rho_ch rho(c2v_0); rho(total) = rho(v2c_0) rho(c2v_0) <= 1: decision 1.
+// Returns the sign words (bit 31 = the decision); ta / tb = rho(total).
+__device__ __forceinline__ void vn2_pair(char *msg, uint32_t packed_a, uint32_t packed_b, double ra, double rb, Track &t, uint32_t &sga,
+                                         uint32_t &sgb, double &ta, double &tb)
+{
+    asm volatile("" : "+v"(packed_a), "+v"(packed_b)); // unpack here, every pass (unpacked offsets would stay live)
+    const uint32_t a0 = packed_a & 0xFFFFu, a1 = packed_a >> 16, b0 = packed_b & 0xFFFFu, b1 = packed_b >> 16;
+    const double ca0 = __builtin_fabs(*at(msg, a0)), ca1 = __builtin_fabs(*at(msg, a1));
+    const double cb0 = __builtin_fabs(*at(msg, b0)), cb1 = __builtin_fabs(*at(msg, b1));
+    const double oa0 = ra * ca1, oa1 = ra * ca0, ob0 = rb * cb1, ob1 = rb * cb0;
+    ta = oa0 * ca0, tb = ob0 * cb0;
+    sga = ta <= 1.0 ? 0x80000000u : 0u, sgb = tb <= 1.0 ? 0x80000000u : 0u;
+    track2(t, oa0, oa1);
+    track2(t, ob0, ob1);
+    *at(msg, a0) = with_sign(oa0, sga), *at(msg, a1) = with_sign(oa1, sga);
+    *at(msg, b0) = with_sign(ob0, sgb), *at(msg, b1) = with_sign(ob1, sgb);
+}
+
+__device__ __forceinline__ void vn2_one(char *msg, uint32_t packed_a, double ra, Track &t, uint32_t &sga, double &ta)
+{
+    asm volatile("" : "+v"(packed_a));
+    const uint32_t a0 = packed_a & 0xFFFFu, a1 = packed_a >> 16;
+    const double ca0 = __builtin_fabs(*at(msg, a0)), ca1 = __builtin_fabs(*at(msg, a1));
+    const double oa0 = ra * ca1, oa1 = ra * ca0;
+    ta = oa0 * ca0;
+    sga = ta <= 1.0 ? 0x80000000u : 0u;
+    track2(t, oa0, oa1);
+    *at(msg, a0) = with_sign(oa0, sga), *at(msg, a1) = with_sign(oa1, sga);
+}
+
+// degree DV in 3..15, slot offsets in registers (16 bits each, two per word): the wave's first block.  lambda(total) =
+// lambda_ch prod lambda(c2v_p) in column file order (decoder.cpp:50-56), range-checked at every third factor when the
+// product is longer than four; rho(v2c_p) = lambda(c2v_p) / lambda(total).  Returns lambda(total).
+template <int DV>
+__device__ __forceinline__ double vn_wide(char *msg, const uint32_t (&packed)[8], double lam, Track &t, uint32_t &sg)
+{
+    uint32_t pk[(DV + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (DV + 1) / 2; ++i)
+    {
+        pk[i] = packed[i];
+        asm volatile("" : "+v"(pk[i])); // the words stay packed across passes
+    }
+    auto slot = [&](int p) { return at(msg, (p & 1) ? pk[p >> 1] >> 16 : pk[p >> 1] & 0xFFFFu); };
+    double c[DV];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        c[p] = __builtin_fabs(*slot(p));
+    double prod = lam;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+    {
+        prod *= c[p];
+        if (DV > 3 && p % 3 == 2)
+            track(t, prod);
+    }
+    sg = prod >= 1.0 ? 0x80000000u : 0u;
+    const double tot = dm_ratio_div(1.0, prod);
+#pragma unroll
+    for (int p = 0; p + 1 < DV; p += 2)
+    {
+        const double o0 = tot * c[p], o1 = tot * c[p + 1];
+        track2(t, o0, o1);
+        *slot(p) = with_sign(o0, sg), *slot(p + 1) = with_sign(o1, sg);
+    }
+    if constexpr (DV % 2 == 1)
+    {
+        const double o = tot * c[DV - 1];
+        track(t, o);
+        *slot(DV - 1) = with_sign(o, sg);
+    }
+    return prod;
+}
+
+// any degree >= 3 through the plan's table of slot offsets (rolled: every message is read twice; blocks that are neither
+// the wave's first nor of degree 2 — none in the n = 1024 code)
+__device__ __forceinline__ double vn_table(char *msg, const uint32_t *idx, int count, int degree, double lam, Track &t, uint32_t &sg)
+{
+    double prod = lam;
+    for (int p = 0; p < degree; ++p)
+    {
+        prod *= __builtin_fabs(*at(msg, idx[p * count]));
+        if (degree > 3 && p % 3 == 2)
+            track(t, prod);
+    }
+    sg = prod >= 1.0 ? 0x80000000u : 0u;
+    const double tot = dm_ratio_div(1.0, prod);
+    for (int p = 0; p < degree; ++p)
+    {
+        double *m = at(msg, idx[p * count]);
+        const double o = tot * __builtin_fabs(*m);
+        track(t, o);
+        *m = with_sign(o, sg);
+    }
+    return prod;
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- the frame's channel values, one stage entry {lambda, rho} per transmitted bit (AWGN / BSC) or per column (given LLRs) ----
+// AWGN: normal g of the stream is element (g & 1) of accepted polar pair g >> 1; the pairs lie in one slab per generator
+// chunk (kernels.hpp, DecodeArgs).  Element i of the frame (g = g0 + i) sits at word p0[i + (i >= t1 ? d1 : 0) + (i >= t2 ?
+// d2 : 0)]: everything but the two comparisons is wave-uniform.
+struct AwgnFrame
+{
+    const uint64_t *p0;
+    uint32_t t1, t2, d1, d2;
+    bool ok;
+};
+__device__ __forceinline__ AwgnFrame awgn_frame(const DecodeArgs &a, uint64_t frame, int nct)
+{
+    AwgnFrame f;
+    const uint64_t g0 = a.normal_base + frame * static_cast<uint64_t>(nct);
+    const uint64_t q_lo = g0 >> 1, q_hi = (g0 + nct - 1) >> 1;
+    const auto cum = uniform_table(a.slab_cum);
+    const uint64_t rel_lo = q_lo - a.pair_origin, rel_hi = q_hi - a.pair_origin;
+    uint32_t j0 = static_cast<uint32_t>(static_cast<float>(rel_lo) * a.slab_pairs_inv);
+    j0 = j0 < a.n_slabs ? j0 : a.n_slabs - 1;
+    uint32_t jb = j0 > 0 ? j0 - 1 : 0;
+    uint64_t c0 = cum[jb], c1 = cum[jb + 1], c2 = cum[jb + 2], c3 = cum[jb + 3];
+    if (!(c0 <= rel_lo && rel_hi < c3)) // (a guess off by more than one slab: walk the table)
+    {
+        while (j0 > 0 && rel_lo < cum[j0])
+            --j0;
+        while (j0 + 1 < a.n_slabs && rel_lo >= cum[j0 + 1])
+            ++j0;
+        jb = j0;
+        c0 = cum[jb], c1 = cum[jb + 1], c2 = cum[jb + 2], c3 = cum[jb + 3];
+    }
+    f.ok = c0 <= rel_lo && rel_hi < c3; // (a frame over more than three slabs: left to the general kernel)
+    auto threshold = [&](uint64_t c) -> uint32_t { // first i with ((g0 + i) >> 1) - origin >= c
+        if (c <= rel_lo)
+            return 0u;
+        const uint64_t dlt = c - rel_lo;
+        return dlt > 0x3FFFFFFFull ? 0x7FFFFFFFu : static_cast<uint32_t>(2 * dlt - (g0 & 1));
+    };
+    f.t1 = threshold(c1), f.t2 = threshold(c2);
+    f.p0 = a.pairs + (static_cast<uint64_t>(jb) * a.slab_words + g0 - 2 * (a.pair_origin + c0));
+    f.d1 = static_cast<uint32_t>(a.slab_words - 2 * (c1 - c0));
+    f.d2 = static_cast<uint32_t>(a.slab_words - 2 * (c2 - c1));
+    return f;
+}
+
+// =======================================================================================================================
+template <bool WANT_LLR, int VNB, int CNL>
+__device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPlan &F)
+{
+    extern __shared__ double lds[];
+    __shared__ int misc[4];
+    __shared__ int votes[2][kDecodeWaves];
+    const DevPlan &P = a.plan;
+    const int nc = P.nc, nct = P.nct;
+    const uint64_t frame = blockIdx.x;
+    char *msg = reinterpret_cast<char *>(lds);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_amdgcn_s_setprio(LDPC_AMD_DECODE_PRIO); // (kernels.hip: the noise generator's waves share the compute units)
+    const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
+    if (tid == 0)
+        misc[0] = 0;
+    Track t{DM_BOX_LO_WORD, DM_BOX_LO_WORD, 0u};
+
+    // ---- prologue, part 1: stage entries {lambda, rho} ----
+    const bool given = a.mode == kModeLlr;
+    const int n_stage = given ? nc : nct;
+    double2 *stage = reinterpret_cast<double2 *>(lds);
+    {
+        auto put = [&](int s, double L) {
+            if (!(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT))
+                t.hmax = 0xFFFFFFFFu; // the frame leaves the ratio form at once
+            const double lam = dm_exp_clamped(0.0 - L);
+            stage[s] = double2{lam, dm_ratio_div(1.0, lam)};
+        };
+        double *dump = a.llr_in_dump ? a.llr_in_dump + frame * nc : nullptr;
+        if (dump && !given) // columns the channel does not write: punctured 0.0, shortened (channel.cpp:73-86)
+            for (int r = tid; r < nc; r += kThreads)
+                if (const uint8_t k = P.rank_kind[r]; k != 0)
+                    dump[P.rank_col[r]] = k == 2 ? a.shorten_llr : 0.0;
+        if (given)
+        {
+            const double *in = a.llr_in + frame * nc;
+            for (int s = tid; s < n_stage; s += kThreads)
+            {
+                const double L = in[s];
+                if (dump)
+                    dump[s] = L;
+                put(s, L);
+            }
+        }
+        else if (a.mode == kModeAwgn)
+        {
+            const AwgnFrame f = awgn_frame(a, frame, nct);
+            if (!f.ok)
+                t.hmax = 0xFFFFFFFFu;
+            else
+                for (int i = tid; i < n_stage; i += kThreads)
+                {
+                    const uint32_t ui = static_cast<uint32_t>(i);
+                    const uint32_t off = ui + (ui >= f.t1 ? f.d1 : 0u) + (ui >= f.t2 ? f.d2 : 0u);
+                    const uint64_t w = __builtin_nontemporal_load(f.p0 + off);
+                    int xb = 0;
+                    int col = 0;
+                    if (cw || dump)
+                        col = P.bit_pos[i];
+                    if (cw)
+                        xb = static_cast<int>(cw[col]);
+                    const double noise = dm_from_bits(w) * a.sigma + 0.0; // channel.cpp:62-68
+                    const double xs = cw ? static_cast<double>(1 - 2 * xb) : 1.0;
+                    const double y = noise + xs;
+                    const double L = 2 * y / a.sigma2; // channel.cpp:88-92
+                    if (dump)
+                        dump[col] = L;
+                    put(i, L);
+                }
+        }
+        else // kModeBsc (channel.cpp:129-162)
+        {
+            const uint64_t *raw = a.raw + frame * static_cast<uint64_t>(nct);
+            for (int i = tid; i < n_stage; i += kThreads)
+            {
+                int xb = 0, col = 0;
+                if (cw || dump)
+                    col = P.bit_pos[i];
+                if (cw)
+                    xb = static_cast<int>(cw[col]);
+                const int flip = canonical(raw[i]) < a.eps;
+                const int y = xb ^ flip;
+                const double L = a.delta * static_cast<double>(1 - 2 * y);
+                if (dump)
+                    dump[col] = L;
+                put(i, L);
+            }
+        }
+        if (tid == kThreads - 1)
+        {
+            if (F.has_shortened && !given)
+                put(n_stage, a.shorten_llr);
+            stage[n_stage + 1] = double2{1.0, 1.0}; // L = 0: punctured, never written by the channel, no node
+        }
+    }
+
+    // what the lane keeps for the whole decode: slot offsets, and (after the barrier) channel values
+    const uint32_t *tab = F.lane_tab + (static_cast<uint32_t>(wave) * kFusedLaneRows) * kWaveSize + lane;
+    const auto my_vdesc = uniform_table(F.vn_desc + wave * kFusedVnSlots * 4);
+    auto vn_cnt = [&](int w) { return my_vdesc[4 * w] & 0xFFFFu; };
+    auto vn_deg = [&](int w) { return my_vdesc[4 * w] >> 16; };
+    uint32_t my_idx[VNB + 1], wide_idx[8], vn_entry[VNB], leaf_entry[2 * CNL];
+#pragma unroll
+    for (int w = 0; w < VNB; ++w)
+        my_idx[w] = tab[w * kWaveSize];
+    my_idx[VNB] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        wide_idx[i] = tab[(8 + i) * kWaveSize];
+    const uint32_t none_entry = static_cast<uint32_t>(n_stage + 1) * 16u;
+#pragma unroll
+    for (int w = 0; w < VNB; ++w)
+    {
+        if (given)
+        {
+            const uint32_t cwd = tab[(24 + w) * kWaveSize];
+            vn_entry[w] = cwd == kFusedNone ? none_entry : (cwd & 0x3FFFFFFFu) * 16u;
+        }
+        else
+            vn_entry[w] = tab[(16 + w) * kWaveSize];
+    }
+#pragma unroll
+    for (int c = 0; c < 2 * CNL; ++c)
+    {
+        if (given)
+        {
+            const uint32_t cwd = tab[(36 + c) * kWaveSize];
+            leaf_entry[c] = cwd == kFusedNone ? none_entry : (cwd & 0x3FFFFFFFu) * 16u;
+        }
+        else
+            leaf_entry[c] = tab[(32 + c) * kWaveSize];
+    }
+    __syncthreads();
+
+    // ---- prologue, part 2: every lane picks up its values; first v2c messages (decoder.cpp:16-19): rho_ch ----
+    double my_val[VNB + 1]; // degree 2: rho_ch; degree >= 3: lambda_ch
+    double leaf_rho[2 * CNL];
+    double first_v2c[VNB];
+    my_val[VNB] = 1.0;
+#pragma unroll
+    for (int w = 0; w < VNB; ++w)
+    {
+        const double2 e = *reinterpret_cast<const double2 *>(msg + vn_entry[w]);
+        first_v2c[w] = e.y;
+        my_val[w] = vn_deg(w) == 2 ? e.y : e.x; // (wave-uniform)
+    }
+#pragma unroll
+    for (int c = 0; c < 2 * CNL; ++c)
+        leaf_rho[c] = reinterpret_cast<const double2 *>(msg + leaf_entry[c])->y;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < VNB; ++w)
+    {
+        const int cnt = vn_cnt(w), deg = vn_deg(w);
+        if (lane >= cnt)
+            continue;
+        if (deg == 2)
+        {
+            *at(msg, my_idx[w] & 0xFFFFu) = first_v2c[w];
+            *at(msg, my_idx[w] >> 16) = first_v2c[w];
+        }
+        else if (w == 0 && deg <= 15)
+        {
+#pragma unroll
+            for (int q = 0; q < 15; ++q)
+                if (q < deg)
+                    *at(msg, (wide_idx[q >> 1] >> (16 * (q & 1))) & 0xFFFFu) = first_v2c[w];
+        }
+        else
+        {
+            const uint32_t *idx = F.vn_slot + my_vdesc[4 * w + 1] + lane;
+            for (int p = 0; p < deg; ++p)
+                *at(msg, idx[p * cnt]) = first_v2c[w];
+        }
+    }
+    __syncthreads();
+
+    const auto my_leaf_calls = uniform_table(reinterpret_cast<const uint32_t *>(F.leaf_calls + wave * kFusedLeafCalls));
+    const auto my_calls = uniform_table(reinterpret_cast<const uint32_t *>(F.calls + wave * F.calls_stride));
+    double *out_llr = WANT_LLR ? a.llr_out + frame * nc : nullptr;
+    uint32_t leaf_bits = 0; // bit 2c + h: decision of this lane's leaf in block h of leaf call c, as of the previous pass
+    uint32_t vn_bits = 0;   // bit w: decision of this lane's node in slot w
+    [[maybe_unused]] double leaf_tot[2 * CNL];
+    uint32_t I = 0;
+    for (;;)
+    {
+        // ---- loop pass I: check-node pass I, which also sees — in the sign bits of its inputs and the leaf bits — the
+        // syndrome of the decisions of variable-node pass I-1 (decoder.cpp:25-45, decoder.h:47-64) ----
+        uint32_t bad = 0, new_leaf_bits = 0;
+#pragma unroll
+        for (int c = 0; c < CNL; ++c)
+        {
+            const uint32_t offs = my_leaf_calls[4 * c], cnts = my_leaf_calls[4 * c + 1], cls = my_leaf_calls[4 * c + 2];
+            const uint32_t cnt0 = cnts & 0xFFFFu;
+            if (cnt0 == 0)
+                continue;
+            const bool two = (cnts >> 16) != 0;
+            uint32_t lb0 = 0, lb1 = 0;
+            const uint32_t prev0 = leaf_bits << (31 - 2 * c), prev1 = leaf_bits << (30 - 2 * c);
+            double tot0 = 1.0, tot1 = 1.0;
+            uint32_t par = 0;
+#define LDPC_LEAF_CLASS(D, NM)                                                                                                                 \
+    case cls_key(D, 1, NM):                                                                                                                    \
+        if (two)                                                                                                                               \
+            par = cnf_call<D, true, cls_flip(D, 1, NM), true, WANT_LLR>(msg, offs & 0xFFFFu, offs >> 16, cnt0, lane, leaf_rho[2 * c],          \
+                                                                        leaf_rho[2 * c + 1], prev0, prev1, lb0, lb1, t, tot0, tot1);           \
+        else if (lane < static_cast<int>(cnt0))                                                                                                \
+            par = cnf_call<D, true, cls_flip(D, 1, NM), false, WANT_LLR>(msg, offs & 0xFFFFu, 0, cnt0, lane, leaf_rho[2 * c],                  \
+                                                                         leaf_rho[2 * c + 1], prev0, prev1, lb0, lb1, t, tot0, tot1);          \
+        break;
+            switch (cls) // wave-uniform
+            {
+                LDPC_LEAF_CLASS(3, 0)
+                LDPC_LEAF_CLASS(3, 1)
+                LDPC_LEAF_CLASS(3, 2)
+                LDPC_LEAF_CLASS(4, 0)
+                LDPC_LEAF_CLASS(4, 1)
+                LDPC_LEAF_CLASS(4, 2)
+                LDPC_LEAF_CLASS(4, 3)
+            default: break;
+            }
+#undef LDPC_LEAF_CLASS
+            bad |= par;
+            new_leaf_bits |= (lb0 << (2 * c)) | (lb1 << (2 * c + 1));
+            if constexpr (WANT_LLR)
+                leaf_tot[2 * c] = tot0, leaf_tot[2 * c + 1] = tot1;
+        }
+        for (int c = 0; c < F.calls_stride; ++c)
+        {
+            const uint32_t offs = my_calls[4 * c], cnts = my_calls[4 * c + 1], cls = my_calls[4 * c + 2];
+            const uint32_t cnt0 = cnts & 0xFFFFu;
+            if (cnt0 == 0)
+                break;
+            const bool two = (cnts >> 16) != 0;
+            uint32_t lb0, lb1;
+            double tot0, tot1;
+            uint32_t par = 0;
+#define LDPC_CLASS(D, NM)                                                                                                                      \
+    case cls_key(D, 0, NM):                                                                                                                    \
+        if (two)                                                                                                                               \
+            par = cnf_call<D, false, cls_flip(D, 0, NM), true, false>(msg, offs & 0xFFFFu, offs >> 16, cnt0, lane, 0.0, 0.0, 0u, 0u, lb0, lb1, \
+                                                                      t, tot0, tot1);                                                          \
+        else if (lane < static_cast<int>(cnt0))                                                                                                \
+            par = cnf_call<D, false, cls_flip(D, 0, NM), false, false>(msg, offs & 0xFFFFu, 0, cnt0, lane, 0.0, 0.0, 0u, 0u, lb0, lb1, t,      \
+                                                                       tot0, tot1);                                                            \
+        break;
+            switch (cls) // wave-uniform
+            {
+                LDPC_CLASS(2, 0)
+                LDPC_CLASS(2, 1)
+                LDPC_CLASS(2, 2)
+                LDPC_CLASS(3, 0)
+                LDPC_CLASS(3, 1)
+                LDPC_CLASS(3, 2)
+                LDPC_CLASS(3, 3)
+                LDPC_CLASS(4, 0)
+                LDPC_CLASS(4, 1)
+                LDPC_CLASS(4, 2)
+                LDPC_CLASS(4, 3)
+                LDPC_CLASS(4, 4)
+            default: break;
+            }
+#undef LDPC_CLASS
+            bad |= par;
+        }
+        const int ph = I & 1;
+        const bool esc = dm_box_escaped(t.hmax, t.hmin) || t.pmax >= DM_FUSED_P_HI;
+        const int wave_vote = (__ballot((bad & 0x80000000u) != 0) != 0) | ((__ballot(esc) != 0) << 1);
+        if (lane == 0)
+            votes[ph][wave] = wave_vote;
+        __syncthreads();
+        int any = 0;
+#pragma unroll
+        for (int w = 0; w < kDecodeWaves; ++w)
+            any |= votes[ph][w];
+        if (any & 2) // checked before the syndrome: an escaped frame's hard decisions mean nothing
+        {
+            if (tid == 0)
+            {
+                const uint32_t pos = atomicAdd(a.redo_count, 1u);
+                a.redo_list[pos] = static_cast<uint32_t>(frame);
+            }
+            return;
+        }
+        if (I > 0 && a.early_term && !(any & 1)) // decoder.cpp:66-72 after variable-node pass I-1
+        {
+            --I;
+            break;
+        }
+        if (I == a.iterations)
+            break;
+        leaf_bits = new_leaf_bits; // the leaves' decisions of pass I (decoder.cpp:58 for a node of degree 1)
+        if constexpr (WANT_LLR)
+        {
+#pragma unroll
+            for (int c = 0; c < 2 * CNL; ++c)
+                if (const uint32_t cwd = tab[(36 + c) * kWaveSize]; cwd != kFusedNone)
+                    out_llr[cwd & 0x3FFFFFFFu] = 0.0 - dm_log(leaf_tot[c]);
+        }
+
+        // ---- variable-node pass I, APP and hard decision: decoder.cpp:48-64 ----
+        uint32_t bits = 0;
+        auto note = [&](int w, uint32_t sg) { bits |= (sg >> 31) << w; };
+        [[maybe_unused]] auto put_llr = [&](int w, double llr) {
+            if constexpr (WANT_LLR)
+                out_llr[tab[(24 + w) * kWaveSize] & 0x3FFFFFFFu] = llr;
+        };
+        auto one = [&](int w) {
+            const int cnt = vn_cnt(w), deg = vn_deg(w);
+            if (lane >= cnt)
+                return;
+            uint32_t sg;
+            if (deg == 2)
+            {
+                double tt;
+                vn2_one(msg, my_idx[w], my_val[w], t, sg, tt);
+                put_llr(w, dm_log(tt));
+            }
+            else
+            {
+                double prod = 1.0;
+                if (w == 0 && deg <= 15)
+                    switch (deg) // wave-uniform
+                    {
+#define LDPC_VN(DV) \
+    case DV: prod = vn_wide<DV>(msg, wide_idx, my_val[0], t, sg); break;
+                        LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8) LDPC_VN(9)
+                        LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15)
+#undef LDPC_VN
+                    default: sg = 0; break;
+                    }
+                else
+                    prod = vn_table(msg, F.vn_slot + my_vdesc[4 * w + 1] + lane, cnt, deg, my_val[w], t, sg);
+                put_llr(w, 0.0 - dm_log(prod));
+            }
+            note(w, sg);
+        };
+#pragma unroll
+        for (int w = 0; w < VNB; w += 2)
+        {
+            if (w + 1 < VNB && vn_deg(w) == 2 && vn_deg(w + 1) == 2 && vn_cnt(w) == kWaveSize && vn_cnt(w + 1) == kWaveSize)
+            {
+                uint32_t sga, sgb;
+                double ta, tb;
+                vn2_pair(msg, my_idx[w], my_idx[w + 1], my_val[w], my_val[w + 1], t, sga, sgb, ta, tb);
+                note(w, sga), note(w + 1, sgb);
+                put_llr(w, dm_log(ta)), put_llr(w + 1, dm_log(tb));
+            }
+            else
+            {
+                one(w);
+                if (w + 1 < VNB)
+                    one(w + 1);
+            }
+        }
+        vn_bits = bits;
+        __syncthreads();
+        ++I;
+    }
+
+    // ---- outputs: iteration count (decoder.cpp:74-77), hard decisions, bit errors (ldpcsim.cpp:184-188) ----
+    if (tid == 0 && a.iters)
+        a.iters[frame] = I;
+    uint8_t *hard = a.hard ? a.hard + frame * nc : nullptr;
+    int err = 0;
+    if (hard || a.bit_errors)
+    {
+        auto account = [&](uint32_t cwd, uint32_t bit) {
+            if (cwd == kFusedNone)
+                return;
+            const uint32_t col = cwd & 0x3FFFFFFFu;
+            if (hard)
+                hard[col] = static_cast<uint8_t>(bit);
+            if (cwd & kFusedCounted)
+                err += static_cast<int>(bit) != (cw ? static_cast<int>(cw[col]) : 0);
+        };
+#pragma unroll
+        for (int w = 0; w < VNB; ++w)
+            account(tab[(24 + w) * kWaveSize], (vn_bits >> w) & 1u);
+#pragma unroll
+        for (int c = 0; c < 2 * CNL; ++c)
+            account(tab[(36 + c) * kWaveSize], (leaf_bits >> c) & 1u);
+    }
+    if (a.bit_errors)
+    {
+        err = wave_sum(err);
+        if (lane == 0 && err)
+            atomicAdd(&misc[0], err);
+        __syncthreads();
+        if (tid == 0)
+            a.bit_errors[frame] = static_cast<uint32_t>(misc[0]);
+    }
+}
+
+// the instantiation of the n = 1024 code (at most four variable-node blocks and one leaf call per wave, no LLR output) is
+// compiled for LDPC_AMD_FUSED_WAVES waves per SIMD = that many frames per CU (its messages take 23 KB of LDS)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(LDPC_AMD_FUSED_WAVES, LDPC_AMD_FUSED_WAVES))) void
+decode_fused_small(const DecodeArgs a, const DevFusedPlan f)
+{
+    fused_body<false, 4, 1>(a, f);
+}
+
+template <bool WANT_LLR, int VNB, int CNL>
+__global__ __launch_bounds__(kThreads) void decode_fused_kernel(const DecodeArgs a, const DevFusedPlan f)
+{
+    fused_body<WANT_LLR, VNB, CNL>(a, f);
+}
+
+} // namespace
+
+int launch_decode_fused(const DecodeArgs &a, const DevFusedPlan &f, void *stream)
+{
+    if (a.n_frames == 0)
+        return hipSuccess;
+    if (!a.redo_list || !a.redo_count || a.redo_count_in || !a.early_term || a.iterations == 0 || a.ratio_separate)
+        return hipErrorInvalidValue;
+    if (f.vnb > kFusedVnSlots || f.cnl > kFusedLeafCalls)
+        return hipErrorInvalidValue;
+    const bool want_llr = a.llr_out != nullptr;
+    void (*k)(const DecodeArgs, const DevFusedPlan) = nullptr;
+    if (f.vnb <= 4 && f.cnl <= 1)
+        k = want_llr ? decode_fused_kernel<true, 4, 1> : decode_fused_small;
+    else
+        k = want_llr ? decode_fused_kernel<true, kFusedVnSlots, kFusedLeafCalls> : decode_fused_kernel<false, kFusedVnSlots, kFusedLeafCalls>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(f.lds_bytes));
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(a.n_frames)), dim3(kThreads), f.lds_bytes, static_cast<hipStream_t>(stream), a, f);
+    return hipGetLastError();
+}
+
+} // namespace ldpc_amd

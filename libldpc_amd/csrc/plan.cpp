@@ -1,9 +1,12 @@
 // plan.cpp — builds the device execution plan (see plan.hpp).
 #include "plan.hpp"
 
+#include "fused_rule.h"
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <numeric>
 #include <stdexcept>
 
@@ -475,6 +478,271 @@ Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc,
     }
     r.ok = true;
     return r;
+}
+
+// Plan of the fused form (plan.hpp, detmath.h "Fused form"): check-node blocks by class with their inputs in the rule's
+// order, message slots for the edges that do not end in a leaf, calls dealt to the waves by cost.
+FusedPlan build_fused_plan(const LdpcCode &code, const Plan &plan)
+{
+    FusedPlan f;
+    const SparseGF2 &H = code.H;
+    if (!plan.lds_ok || plan.has_isolated_vn || H.rows <= 0 ||
+        !dm_fused_applies(H.rows, H.cols, H.rptr.data(), H.rcol.data(), H.cptr.data()))
+        return f;
+    const int W = kDecodeWaves;
+    auto cdeg = [&](int c) { return H.cptr[c + 1] - H.cptr[c]; };
+
+    // ---- check nodes by class (key order), rows in file order inside a class, blocks of <= 64 ----
+    struct Row
+    {
+        int row, order[4];
+    };
+    std::map<unsigned, std::vector<Row>> by_class;
+    for (int i = 0; i < H.rows; ++i)
+    {
+        Row r{i, {0, 0, 0, 0}};
+        unsigned flip;
+        int leaf;
+        const int d = H.rptr[i + 1] - H.rptr[i];
+        if (!dm_fused_row_order(d, H.rcol.data() + H.rptr[i], H.cptr.data(), r.order, &flip, &leaf))
+            return f;
+        by_class[dm_fused_class(d, flip, leaf)].push_back(r);
+    }
+    struct Block
+    {
+        unsigned cls;
+        uint32_t off; // first slot (in messages)
+        std::vector<Row> rows;
+    };
+    std::vector<Block> blocks;
+    f.edge_slot.assign(plan.nnz, kNoSlot);
+    uint32_t slot = 0;
+    for (auto &[cls, rows] : by_class)
+    {
+        const int d = static_cast<int>(cls & 7u), leaf = static_cast<int>((cls >> 3) & 1u), m = d - leaf;
+        for (size_t i = 0; i < rows.size(); i += kWaveSize)
+        {
+            Block b{cls, slot, {}};
+            b.rows.assign(rows.begin() + i, rows.begin() + std::min(rows.size(), i + kWaveSize));
+            const uint32_t cnt = static_cast<uint32_t>(b.rows.size());
+            for (uint32_t l = 0; l < cnt; ++l)
+                for (int k = 0; k < m; ++k)
+                    f.edge_slot[H.redge[H.rptr[b.rows[l].row] + b.rows[l].order[k]]] = slot + k * cnt + l;
+            slot += static_cast<uint32_t>(m) * cnt;
+            blocks.push_back(std::move(b));
+        }
+    }
+    f.n_slots = static_cast<int>(slot);
+    if (f.n_slots > DM_FUSED_MAX_SLOTS)
+        return f;
+
+    // ---- calls: consecutive full blocks of a class two at a time ----
+    struct Call
+    {
+        int b0, b1; // block ids (b1 = -1: one block)
+        int cost;
+        bool leaf;
+    };
+    auto class_cost = [](unsigned cls) {
+        const int d = static_cast<int>(cls & 7u), leaf = static_cast<int>((cls >> 3) & 1u);
+        return d == 2 ? 12 : (d == 3 ? (leaf ? 28 : 30) : (leaf ? 45 : 50));
+    };
+    std::vector<Call> calls;
+    for (size_t b = 0; b < blocks.size();)
+    {
+        const bool pair = b + 1 < blocks.size() && blocks[b + 1].cls == blocks[b].cls && blocks[b].rows.size() == kWaveSize &&
+                          blocks[b + 1].rows.size() == kWaveSize;
+        const bool leaf = (blocks[b].cls >> 3) & 1u;
+        calls.push_back(Call{static_cast<int>(b), pair ? static_cast<int>(b + 1) : -1, class_cost(blocks[b].cls) * (pair ? 2 : 1) + 4, leaf});
+        b += pair ? 2 : 1;
+    }
+    // leaf calls first (each wave takes its share: they sit in register-backed slots), then the rest by cost
+    std::vector<std::vector<int>> w_leaf(W), w_rest(W);
+    std::vector<long> load(W, 0);
+    {
+        std::vector<int> order(calls.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return calls[a].cost > calls[b].cost; });
+        int n_leaf = 0;
+        for (const Call &c : calls)
+            n_leaf += c.leaf;
+        const int leaf_cap = (n_leaf + W - 1) / W;
+        if (leaf_cap > kFusedLeafCalls)
+            return f;
+        for (int ci : order)
+            if (calls[ci].leaf)
+            {
+                int best = -1;
+                for (int w = 0; w < W; ++w)
+                    if (static_cast<int>(w_leaf[w].size()) < leaf_cap && (best < 0 || load[w] < load[best]))
+                        best = w;
+                w_leaf[best].push_back(ci);
+                load[best] += calls[ci].cost;
+            }
+        for (int ci : order)
+            if (!calls[ci].leaf)
+            {
+                const int w = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
+                w_rest[w].push_back(ci);
+                load[w] += calls[ci].cost;
+            }
+        f.cnl = leaf_cap;
+    }
+    auto describe = [&](const Call &c) {
+        const Block &b0 = blocks[c.b0];
+        FusedCall d{b0.off * 8u, static_cast<uint32_t>(b0.rows.size()), b0.cls, 0};
+        if (c.b1 >= 0)
+        {
+            d.offs |= (blocks[c.b1].off * 8u) << 16;
+            d.cnts |= static_cast<uint32_t>(blocks[c.b1].rows.size()) << 16;
+        }
+        return d;
+    };
+    f.leaf_calls.assign(static_cast<size_t>(W) * kFusedLeafCalls, FusedCall{0, 0, 0, 0});
+    f.calls_stride = 1;
+    for (int w = 0; w < W; ++w)
+        f.calls_stride = std::max(f.calls_stride, static_cast<int>(w_rest[w].size()) + 1);
+    f.calls.assign(static_cast<size_t>(W) * f.calls_stride, FusedCall{0, 0, 0, 0});
+    for (int w = 0; w < W; ++w)
+    {
+        for (size_t i = 0; i < w_leaf[w].size(); ++i)
+            f.leaf_calls[static_cast<size_t>(w) * kFusedLeafCalls + i] = describe(calls[w_leaf[w][i]]);
+        for (size_t i = 0; i < w_rest[w].size(); ++i)
+            f.calls[static_cast<size_t>(w) * f.calls_stride + i] = describe(calls[w_rest[w][i]]);
+    }
+
+    // ---- variable nodes of degree >= 2: by degree (descending), columns in file order, blocks of <= 64 ----
+    std::vector<int> cols;
+    for (int c = 0; c < H.cols; ++c)
+        if (cdeg(c) >= 2)
+            cols.push_back(c);
+    std::stable_sort(cols.begin(), cols.end(), [&](int a, int b) { return cdeg(a) > cdeg(b); });
+    struct VBlock
+    {
+        int degree;
+        std::vector<int> cols;
+    };
+    std::vector<VBlock> vblocks;
+    for (size_t i = 0; i < cols.size();)
+    {
+        size_t j = i;
+        while (j < cols.size() && j - i < kWaveSize && cdeg(cols[j]) == cdeg(cols[i]))
+            ++j;
+        vblocks.push_back(VBlock{cdeg(cols[i]), std::vector<int>(cols.begin() + i, cols.begin() + j)});
+        i = j;
+    }
+    std::vector<std::vector<int>> w_vn(W);
+    {
+        std::vector<int> order(vblocks.size());
+        std::iota(order.begin(), order.end(), 0);
+        auto cost = [&](int b) { return vblocks[b].degree == 2 ? 13 : 5 * vblocks[b].degree + 8; };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+        std::vector<long> vload(W, 0);
+        for (int b : order)
+        {
+            int best = -1;
+            for (int w = 0; w < W; ++w) // (one slot kept free for the alignment of the degree-2 blocks)
+                if (static_cast<int>(w_vn[w].size()) < kFusedVnSlots - 1 && (best < 0 || vload[w] < vload[best]))
+                    best = w;
+            if (best < 0)
+                for (int w = 0; w < W; ++w)
+                    if (static_cast<int>(w_vn[w].size()) < kFusedVnSlots && (best < 0 || vload[w] < vload[best]))
+                        best = w;
+            if (best < 0)
+                return f;
+            w_vn[best].push_back(b);
+            vload[best] += cost(b);
+        }
+    }
+    // entry of a column's channel value in the staging area, and the flags of its column word
+    std::vector<uint32_t> col_entry(H.cols, static_cast<uint32_t>(plan.nct) + 1u), col_word(H.cols);
+    for (int c = 0; c < H.cols; ++c)
+        col_word[c] = static_cast<uint32_t>(c);
+    for (int i = 0; i < static_cast<int>(code.bit_pos.size()); ++i)
+    {
+        if (i < plan.nct)
+            col_entry[code.bit_pos[i]] = static_cast<uint32_t>(i);
+        col_word[code.bit_pos[i]] |= kFusedCounted;
+    }
+    for (int c : code.shorten) // (after the transmitted ones: a column in both lists is not in bit_pos)
+        if (c >= 0 && c < H.cols && plan.rank_kind[plan.col_rank[c]] == 2)
+            col_entry[c] = static_cast<uint32_t>(plan.nct);
+    f.has_shortened = !code.shorten.empty();
+
+    f.vn_desc.assign(static_cast<size_t>(W) * kFusedVnSlots * 4, 0);
+    f.lane_tab.assign(static_cast<size_t>(W) * kFusedLaneRows * kWaveSize, 0);
+    f.vnb = 1;
+    for (int w = 0; w < W; ++w)
+    {
+        uint32_t *tab = &f.lane_tab[static_cast<size_t>(w) * kFusedLaneRows * kWaveSize];
+        for (int r = 16; r < 24; ++r)
+            std::fill(tab + r * kWaveSize, tab + (r + 1) * kWaveSize, (static_cast<uint32_t>(plan.nct) + 1u) * 16u);
+        for (int r = 32; r < 36; ++r)
+            std::fill(tab + r * kWaveSize, tab + (r + 1) * kWaveSize, (static_cast<uint32_t>(plan.nct) + 1u) * 16u);
+        for (int r = 24; r < 32; ++r)
+            std::fill(tab + r * kWaveSize, tab + (r + 1) * kWaveSize, kFusedNone);
+        for (int r = 36; r < 40; ++r)
+            std::fill(tab + r * kWaveSize, tab + (r + 1) * kWaveSize, kFusedNone);
+        // widest first; the degree-2 blocks from an even slot on
+        std::vector<int> &mine = w_vn[w];
+        std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return vblocks[a].degree > vblocks[b].degree; });
+        std::vector<int> slots;
+        for (int b : mine)
+        {
+            if (vblocks[b].degree == 2 && slots.size() % 2 == 1 && !slots.empty() && slots.back() >= 0 && vblocks[slots.back()].degree != 2 &&
+                mine.size() + 1 <= static_cast<size_t>(kFusedVnSlots))
+                slots.push_back(-1);
+            slots.push_back(b);
+        }
+        if (static_cast<int>(slots.size()) > kFusedVnSlots)
+            return f;
+        f.vnb = std::max(f.vnb, static_cast<int>(slots.size()));
+        for (size_t sw = 0; sw < slots.size(); ++sw)
+        {
+            if (slots[sw] < 0)
+                continue;
+            const VBlock &vb = vblocks[slots[sw]];
+            const uint32_t cnt = static_cast<uint32_t>(vb.cols.size());
+            uint32_t *d = &f.vn_desc[(static_cast<size_t>(w) * kFusedVnSlots + sw) * 4];
+            d[0] = cnt | (static_cast<uint32_t>(vb.degree) << 16);
+            d[1] = static_cast<uint32_t>(f.vn_slot.size());
+            auto eslot = [&](int l, int p) { return f.edge_slot[H.cedge[H.cptr[vb.cols[l]] + p]] * 8u; };
+            const bool in_regs = vb.degree == 2 || (sw == 0 && vb.degree <= 15);
+            if (!in_regs)
+                for (int p = 0; p < vb.degree; ++p)
+                    for (uint32_t l = 0; l < cnt; ++l)
+                        f.vn_slot.push_back(eslot(static_cast<int>(l), p));
+            for (uint32_t l = 0; l < cnt; ++l)
+            {
+                if (vb.degree == 2)
+                    tab[sw * kWaveSize + l] = eslot(l, 0) | (eslot(l, 1) << 16);
+                else if (in_regs)
+                    for (int q = 0; q < vb.degree; ++q)
+                        tab[(8 + q / 2) * kWaveSize + l] |= eslot(l, q) << (16 * (q & 1));
+                tab[(16 + sw) * kWaveSize + l] = col_entry[vb.cols[l]] * 16u;
+                tab[(24 + sw) * kWaveSize + l] = col_word[vb.cols[l]];
+            }
+        }
+        for (size_t c = 0; c < w_leaf[w].size(); ++c)
+            for (int h = 0; h < 2; ++h)
+            {
+                const int bi = h == 0 ? calls[w_leaf[w][c]].b0 : calls[w_leaf[w][c]].b1;
+                if (bi < 0)
+                    continue;
+                const Block &b = blocks[bi];
+                const int d = static_cast<int>(b.cls & 7u);
+                for (size_t l = 0; l < b.rows.size(); ++l)
+                {
+                    const int col = H.rcol[H.rptr[b.rows[l].row] + b.rows[l].order[d - 1]]; // the leaf: the last input
+                    tab[(32 + 2 * c + h) * kWaveSize + l] = col_entry[col] * 16u;
+                    tab[(36 + 2 * c + h) * kWaveSize + l] = col_word[col];
+                }
+            }
+    }
+    if (f.vn_slot.empty())
+        f.vn_slot.push_back(0);
+    f.ok = true;
+    return f;
 }
 
 // Steps of the layered schedule: check nodes in file order within each degree, each put into the first step of its degree

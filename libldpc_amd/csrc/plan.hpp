@@ -187,6 +187,49 @@ struct LayerPlan
 };
 LayerPlan build_layer_plan(const LdpcCode &code, const Plan &plan);
 
+// ---- fused form of the likelihood-ratio iteration (kernels_fused.hip; detmath.h "Fused form", fused_rule.h) ----------
+// First launch of sum-product with early termination for codes the rule takes (check nodes of degree 2..4 with at most one
+// leaf each).  One workgroup (4 waves) per frame as in the LDS-resident decoder, but only edges that do NOT end in a leaf
+// have a message slot, check-node blocks are uniform in CLASS (degree, leaf or not, how many outputs go to degree-2
+// neighbours) with their inputs in the rule's order, and a wave's work is a list of CALLS of one or two blocks.
+//   slot of (block, lane, k-th message input) = off + k * count + lane; all offsets below are BYTE offsets (< 2^16).
+constexpr int kFusedVnSlots = 8;    // variable-node blocks per wave (general instantiation; the small one takes 4)
+constexpr int kFusedLeafCalls = 2;  // calls with leaves per wave (general instantiation; the small one takes 1)
+constexpr int kFusedLaneRows = 40;  // rows of the lane table
+struct FusedCall
+{
+    uint32_t offs; // block 0 | block 1 << 16
+    uint32_t cnts; // nodes in block 0 | nodes in block 1 << 16 (0: a call of one block; both zero: end of list)
+    uint32_t cls;  // dm_fused_class(degree, flip, leaf)
+    uint32_t pad;
+};
+struct FusedPlan
+{
+    bool ok = false;
+    int n_slots = 0;     // message slots
+    int vnb = 0, cnl = 0; // largest number of variable-node blocks / of leaf calls any wave holds
+    bool has_shortened = false;
+    std::vector<FusedCall> leaf_calls; // [kDecodeWaves][kFusedLeafCalls]
+    std::vector<FusedCall> calls;      // [kDecodeWaves][calls_stride], each row ends in a zero entry
+    int calls_stride = 0;
+    // [kDecodeWaves][kFusedVnSlots][4]: nodes | degree << 16, offset into vn_slot, 0, 0 (nodes 0 = none).  Slot 0 holds the
+    // wave's widest block; blocks of degree 2 sit in consecutive slots from an even one on (lock-step pairs).
+    std::vector<uint32_t> vn_desc;
+    std::vector<uint32_t> vn_slot;     // table path (degree >= 3 outside slot 0, or wider than 15): [off + p * count + lane]
+    // [kDecodeWaves][kFusedLaneRows][64], what a lane keeps or needs once per frame:
+    //   rows  0..7   slot w, degree 2: slot of edge 0 | slot of edge 1 << 16
+    //   rows  8..15  slot 0, degree 3..15: slots of edges 2i, 2i+1 in word i
+    //   rows 16..23  slot w: stage entry of the node's channel value (index among the transmitted bits; nct = shortened,
+    //                nct + 1 = punctured / never written / no node), as a byte offset (x 16)
+    //   rows 24..31  slot w: the node's column | kFusedCounted (its bit is one the error count visits); kFusedNone = no node
+    //   rows 32..35  leaf call c, block h (row 32 + 2c + h): stage entry of the leaf's channel value
+    //   rows 36..39  ... and the leaf's column | flags
+    std::vector<uint32_t> lane_tab;
+    std::vector<uint32_t> edge_slot;   // file-order edge -> slot, kNoSlot for an edge that ends in a leaf (tests)
+};
+constexpr uint32_t kFusedCounted = 0x80000000u, kFusedNone = 0xFFFFFFFFu;
+FusedPlan build_fused_plan(const LdpcCode &code, const Plan &plan);
+
 Plan build_plan(const LdpcCode &code);
 // plan for the decode_reg2_kernel<nt, kc, maxd, nv0, nv1> instantiation; ok = false when the code does not fit it
 Reg2Plan build_reg2_plan(const LdpcCode &code, const Plan &plan, int nt, int kc, int maxd, int nv0, int nv1);

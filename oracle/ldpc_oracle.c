@@ -23,6 +23,7 @@
 #endif
 
 #include "../libldpc_amd/csrc/detmath.h"
+#include "../libldpc_amd/csrc/fused_rule.h"
 
 /* ------------------------------------------------------------------------------------ */
 /* sparse matrix with file-order adjacency (sparse.h:8-90)                               */
@@ -801,6 +802,120 @@ static int dec_decode_ratio(dec_t *d, int allow_shared)
     return ret;
 }
 
+/* The fused form (detmath.h "Fused form", fused_rule.h): what the kernels' FIRST launch runs for sum-product with early
+   termination on codes the rule takes — check nodes take their inputs in the rule's order, a leaf's decision is taken by its
+   check node (n >= rho_ch d), degree-2 variable nodes receive rho(c2v) and multiply.  Same schedule as dec_decode_ratio;
+   v2c[] holds rho(v2c) (a leaf's edge: its constant rho_ch), c2v[] holds lambda(c2v), or rho(c2v) on edges into variable
+   nodes of degree 2 (nothing on a leaf's edge).  Returns the iteration count, or -1 when a value left its range. */
+static int fused_applies(const orc_code *c)
+{
+    const spm *H = &c->H;
+    return handover_applies(c) && dm_fused_applies(H->rows, H->cols, H->rptr, H->rnode, H->cptr);
+}
+
+static int dec_decode_fused(dec_t *d)
+{
+    const spm *H = &d->code->H;
+    const int nc = H->cols;
+    double *lam = malloc(8 * (size_t)nc), *rho = malloc(8 * (size_t)nc), *ltot = malloc(8 * (size_t)nc);
+    uint8_t *lbit = malloc((size_t)nc);
+    int escaped = 0, ret = -1;
+    for (int i = 0; i < nc; ++i)
+    {
+        double L = d->llr_in[i];
+        escaped |= !(fabs(L) <= DM_RATIO_LLR_LIMIT);
+        lam[i] = dm_exp_clamped(0.0 - L);
+        rho[i] = 1.0 / lam[i];
+        for (int p = H->cptr[i]; p < H->cptr[i + 1]; ++p)
+            d->v2c[H->cedge[p]] = rho[i];
+    }
+    unsigned I = 0;
+    for (;;)
+    {
+        for (int i = 0; i < H->rows; ++i)
+        {
+            const int cw = H->rptr[i + 1] - H->rptr[i];
+            const int *cn = H->redge + H->rptr[i], *cols = H->rnode + H->rptr[i];
+            int order[4], leaf;
+            unsigned flip;
+            double v[4], tot = 1.0;
+            uint32_t lb = 0, h;
+            if (!dm_fused_row_order(cw, cols, H->cptr, order, &flip, &leaf))
+            {
+                escaped = 1; /* cannot happen: fused_applies */
+                break;
+            }
+            for (int k = 0; k < cw; ++k)
+                v[k] = d->v2c[cn[order[k]]];
+            if (cw == 2)
+                h = dm_cnf2(v, flip);
+            else if (cw == 3)
+                h = dm_cnf3(v, flip, leaf, &lb, &tot);
+            else
+                h = dm_cnf4(v, flip, leaf, &lb, &tot);
+            escaped |= h >= DM_FUSED_P_HI;
+            for (int k = 0; k < cw - leaf; ++k)
+                d->c2v[cn[order[k]]] = v[k];
+            if (leaf)
+                lbit[cols[order[cw - 1]]] = (uint8_t)lb, ltot[cols[order[cw - 1]]] = tot;
+        }
+        if (escaped)
+            break;
+        if (I > 0 && d->early_term && is_codeword(d))
+        {
+            ret = (int)I - 1;
+            break;
+        }
+        if (I == d->iterations)
+        {
+            ret = (int)I;
+            break;
+        }
+        for (int i = 0; i < nc; ++i)
+        {
+            const int deg = H->cptr[i + 1] - H->cptr[i];
+            if (deg == 1) /* the decision its check node took in this pass (decoder.cpp:58 for a node of degree 1) */
+            {
+                d->co[i] = lbit[i];
+                d->llr_out[i] = 0.0 - dm_log(ltot[i]);
+            }
+            else if (deg == 2)
+            {
+                const int e0 = H->cedge[H->cptr[i]], e1 = H->cedge[H->cptr[i] + 1];
+                const double c0 = d->c2v[e0], c1 = d->c2v[e1];
+                const double o0 = rho[i] * c1, o1 = rho[i] * c0, tot = o0 * c0;
+                d->co[i] = (uint8_t)(tot <= 1.0);
+                d->llr_out[i] = dm_log(tot);
+                escaped |= dm_ratio_out_of_range(o0) | dm_ratio_out_of_range(o1);
+                d->v2c[e0] = o0, d->v2c[e1] = o1;
+            }
+            else
+            {
+                double prod = lam[i];
+                for (int k = 0; k < deg; ++k)
+                {
+                    prod *= d->c2v[H->cedge[H->cptr[i] + k]];
+                    if (deg > 3 && k % 3 == 2)
+                        escaped |= dm_ratio_out_of_range(prod);
+                }
+                d->co[i] = (uint8_t)(prod >= 1.0);
+                d->llr_out[i] = 0.0 - dm_log(prod);
+                const double tot = 1.0 / prod;
+                for (int k = 0; k < deg; ++k)
+                {
+                    const int e = H->cedge[H->cptr[i] + k];
+                    const double o = tot * d->c2v[e];
+                    escaped |= dm_ratio_out_of_range(o);
+                    d->v2c[e] = o;
+                }
+            }
+        }
+        ++I;
+    }
+    free(lam), free(rho), free(ltot), free(lbit);
+    return ret;
+}
+
 static int dec_decode_llr(dec_t *d);
 
 /* test introspection: frames the ratio form finished / handed back since the last reset (not thread-safe) */
@@ -825,7 +940,8 @@ static int dec_decode(dec_t *d)
     {
         /* three stages, as the kernels' three launches: shared-reciprocal check nodes; if a value (or a denominator product)
            leaves its range, again from scratch with separately divided outputs; if the box is left there too, the LLR domain */
-        int it = dec_decode_ratio(d, 1);
+        /* (first stage: the fused form where the code's structure admits it, fused_rule.h) */
+        int it = (d->early_term && fused_applies(d->code)) ? dec_decode_fused(d) : dec_decode_ratio(d, 1);
         if (it < 0 && d->early_term && handover_applies(d->code))
         {
             ++g_ratio_second;

@@ -649,6 +649,7 @@ void Engine::upload_plan()
         const FusedPlan &f = fused_plan_;
         dev_fused_.n_slots = f.n_slots, dev_fused_.vnb = f.vnb, dev_fused_.cnl = f.cnl, dev_fused_.calls_stride = f.calls_stride;
         dev_fused_.has_shortened = f.has_shortened ? 1 : 0;
+        std::memcpy(dev_fused_.vn_prog, f.vn_prog, sizeof f.vn_prog);
         // the message slots; the prologue stages one 16-byte entry per transmitted bit or column (+ 2) in the same space
         dev_fused_.lds_bytes = static_cast<uint32_t>(std::max<size_t>(8 * static_cast<size_t>(f.n_slots), 16 * (static_cast<size_t>(std::max(p.nc, p.nct)) + 2)) + 15) & ~15u;
         dev_fused_.leaf_calls = static_cast<const FusedCall *>(up(f.leaf_calls.data(), f.leaf_calls.size() * sizeof(FusedCall)));

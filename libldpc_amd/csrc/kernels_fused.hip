@@ -33,7 +33,7 @@
 #define LDPC_AMD_DECODE_PRIO 3
 #endif
 #ifndef LDPC_AMD_FUSED_WAVES
-#define LDPC_AMD_FUSED_WAVES 4
+#define LDPC_AMD_FUSED_WAVES 5
 #endif
 
 namespace ldpc_amd
@@ -189,20 +189,26 @@ __device__ __forceinline__ double vn_wide(char *msg, const uint32_t (&packed)[8]
             track(t, prod);
     }
     sg = prod >= 1.0 ? 0x80000000u : 0u;
-    const double tot = dm_ratio_div(1.0, prod);
+    // the decision rides in the sign of rho(total): every product below comes out with it (same magnitudes, no per-edge
+    // or); the node's extremes are taken over the signed upper words — all carry the same top bit — and stripped once
+    const double tot = with_sign(dm_ratio_div(1.0, prod), sg);
+    uint32_t nmax = 0u, nmin = 0xFFFFFFFFu;
 #pragma unroll
     for (int p = 0; p + 1 < DV; p += 2)
     {
         const double o0 = tot * c[p], o1 = tot * c[p + 1];
-        track2(t, o0, o1);
-        *slot(p) = with_sign(o0, sg), *slot(p + 1) = with_sign(o1, sg);
+        nmax = max(max(nmax, hi_word(o0)), hi_word(o1));
+        nmin = min(min(nmin, hi_word(o0)), hi_word(o1));
+        *slot(p) = o0, *slot(p + 1) = o1;
     }
     if constexpr (DV % 2 == 1)
     {
         const double o = tot * c[DV - 1];
-        track(t, o);
-        *slot(DV - 1) = with_sign(o, sg);
+        nmax = max(nmax, hi_word(o)), nmin = min(nmin, hi_word(o));
+        *slot(DV - 1) = o;
     }
+    t.hmax = max(t.hmax, nmax & 0x7FFFFFFFu);
+    t.hmin = min(t.hmin, nmin & 0x7FFFFFFFu);
     return prod;
 }
 
@@ -383,6 +389,7 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
     // what the lane keeps for the whole decode: slot offsets, and (after the barrier) channel values
     const uint32_t *tab = F.lane_tab + (static_cast<uint32_t>(wave) * kFusedLaneRows) * kWaveSize + lane;
     const auto my_vdesc = uniform_table(F.vn_desc + wave * kFusedVnSlots * 4);
+    const uint32_t vn_prog = F.vn_prog[wave];
     auto vn_cnt = [&](int w) { return my_vdesc[4 * w] & 0xFFFFu; };
     auto vn_deg = [&](int w) { return my_vdesc[4 * w] >> 16; };
     uint32_t my_idx[VNB + 1], wide_idx[8], vn_entry[VNB], leaf_entry[2 * CNL];
@@ -473,10 +480,17 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
         // ---- loop pass I: check-node pass I, which also sees — in the sign bits of its inputs and the leaf bits — the
         // syndrome of the decisions of variable-node pass I-1 (decoder.cpp:25-45, decoder.h:47-64) ----
         uint32_t bad = 0, new_leaf_bits = 0;
+        // (the tables are read again in every pass, through pointers the compiler cannot see through: hoisted out of the loop,
+        // the descriptors and every condition derived from them sit in scalar registers for the whole decode — more than
+        // there are, and the surplus is spilled to vector-register lanes, v_readlane by v_readlane)
+        auto leaf_calls_now = my_leaf_calls;
+        auto vdesc_now = my_vdesc;
+        uint32_t prog = vn_prog;
+        asm volatile("" : "+s"(leaf_calls_now), "+s"(vdesc_now), "+s"(prog));
 #pragma unroll
         for (int c = 0; c < CNL; ++c)
         {
-            const uint32_t offs = my_leaf_calls[4 * c], cnts = my_leaf_calls[4 * c + 1], cls = my_leaf_calls[4 * c + 2];
+            const uint32_t offs = leaf_calls_now[4 * c], cnts = leaf_calls_now[4 * c + 1], cls = leaf_calls_now[4 * c + 2];
             const uint32_t cnt0 = cnts & 0xFFFFu;
             if (cnt0 == 0)
                 continue;
@@ -591,12 +605,13 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
             if constexpr (WANT_LLR)
                 out_llr[tab[(24 + w) * kWaveSize] & 0x3FFFFFFFu] = llr;
         };
-        auto one = [&](int w) {
-            const int cnt = vn_cnt(w), deg = vn_deg(w);
+        auto one = [&](int w, uint32_t kind) {
+            const uint32_t d0 = vdesc_now[4 * w];
+            const int cnt = static_cast<int>(d0 & 0xFFFFu), deg = static_cast<int>(d0 >> 16);
             if (lane >= cnt)
                 return;
             uint32_t sg;
-            if (deg == 2)
+            if (kind == kFusedVnPair || kind == kFusedVn2)
             {
                 double tt;
                 vn2_one(msg, my_idx[w], my_val[w], t, sg, tt);
@@ -605,7 +620,7 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
             else
             {
                 double prod = 1.0;
-                if (w == 0 && deg <= 15)
+                if (w == 0 && kind == kFusedVnWide)
                     switch (deg) // wave-uniform
                     {
 #define LDPC_VN(DV) \
@@ -616,7 +631,7 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
                     default: sg = 0; break;
                     }
                 else
-                    prod = vn_table(msg, F.vn_slot + my_vdesc[4 * w + 1] + lane, cnt, deg, my_val[w], t, sg);
+                    prod = vn_table(msg, F.vn_slot + vdesc_now[4 * w + 1] + lane, cnt, deg, my_val[w], t, sg);
                 put_llr(w, 0.0 - dm_log(prod));
             }
             note(w, sg);
@@ -624,7 +639,8 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
 #pragma unroll
         for (int w = 0; w < VNB; w += 2)
         {
-            if (w + 1 < VNB && vn_deg(w) == 2 && vn_deg(w + 1) == 2 && vn_cnt(w) == kWaveSize && vn_cnt(w + 1) == kWaveSize)
+            const uint32_t k01 = (prog >> (4 * w)) & 0xFFu; // (wave-uniform)
+            if (k01 == (kFusedVnPair | (kFusedVnPair << 4)))
             {
                 uint32_t sga, sgb;
                 double ta, tb;
@@ -634,9 +650,10 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
             }
             else
             {
-                one(w);
-                if (w + 1 < VNB)
-                    one(w + 1);
+                if (k01 & 0xFu)
+                    one(w, k01 & 0xFu);
+                if (k01 >> 4)
+                    one(w + 1, k01 >> 4);
             }
         }
         vn_bits = bits;

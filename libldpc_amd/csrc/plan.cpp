@@ -708,6 +708,7 @@ FusedPlan build_fused_plan(const LdpcCode &code, const Plan &plan)
             d[1] = static_cast<uint32_t>(f.vn_slot.size());
             auto eslot = [&](int l, int p) { return f.edge_slot[H.cedge[H.cptr[vb.cols[l]] + p]] * 8u; };
             const bool in_regs = vb.degree == 2 || (sw == 0 && vb.degree <= 15);
+            f.vn_prog[w] |= (vb.degree == 2 ? (cnt == kWaveSize ? kFusedVnPair : kFusedVn2) : (in_regs ? kFusedVnWide : kFusedVnTable)) << (4 * sw);
             if (!in_regs)
                 for (int p = 0; p < vb.degree; ++p)
                     for (uint32_t l = 0; l < cnt; ++l)

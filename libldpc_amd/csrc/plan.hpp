@@ -215,6 +215,9 @@ struct FusedPlan
     // [kDecodeWaves][kFusedVnSlots][4]: nodes | degree << 16, offset into vn_slot, 0, 0 (nodes 0 = none).  Slot 0 holds the
     // wave's widest block; blocks of degree 2 sit in consecutive slots from an even one on (lock-step pairs).
     std::vector<uint32_t> vn_desc;
+    // per wave, four bits per slot: what the variable-node pass does there (one scalar word instead of a handful of
+    // loop-invariant conditions per slot that the compiler would keep in scalar registers for the whole decode)
+    uint32_t vn_prog[kDecodeWaves] = {0, 0, 0, 0};
     std::vector<uint32_t> vn_slot;     // table path (degree >= 3 outside slot 0, or wider than 15): [off + p * count + lane]
     // [kDecodeWaves][kFusedLaneRows][64], what a lane keeps or needs once per frame:
     //   rows  0..7   slot w, degree 2: slot of edge 0 | slot of edge 1 << 16
@@ -228,6 +231,7 @@ struct FusedPlan
     std::vector<uint32_t> edge_slot;   // file-order edge -> slot, kNoSlot for an edge that ends in a leaf (tests)
 };
 constexpr uint32_t kFusedCounted = 0x80000000u, kFusedNone = 0xFFFFFFFFu;
+enum : uint32_t { kFusedVnNone = 0, kFusedVnPair = 1 /* degree 2, 64 nodes */, kFusedVn2 = 2 /* degree 2 */, kFusedVnWide = 3 /* slot 0, degree 3..15 */, kFusedVnTable = 4 };
 FusedPlan build_fused_plan(const LdpcCode &code, const Plan &plan);
 
 Plan build_plan(const LdpcCode &code);

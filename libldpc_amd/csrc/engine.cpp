@@ -177,10 +177,12 @@ void *DeviceBuffer::reserve(size_t bytes)
 // ---------------------------------------------------------------------------------------------
 MtDevice::MtDevice()
 {
-    // 2240 blocks = 698 880 words = 5.6 MB of raw stream per chunk: the serial twist chain of a chunk hides under the decode
-    // kernel (whose waves outrank it: at 3360 blocks the chain had become as long as the headline kernel) and a 65 536-frame
-    // batch needs 123 jump-ahead tasks, issued two steps ahead.  LDPC_AMD_CHUNK_BLOCKS: experiments / tests of the chunk edges.
-    chunk_blocks_ = 2240;
+    // 1120 blocks = 349 440 words = 2.8 MB of raw stream per chunk: the serial twist chain of a chunk has to hide under the
+    // decode kernel, whose waves outrank it.  Round 3's headline kernel (3.6 ms) hid chunks of 2240 blocks; under round 4's
+    // (2.6 ms) their chain outlasts it (step 2.95 ms), chunks of 840..1400 blocks all give 2.76..2.79 ms, and at 560 the
+    // jump-ahead tasks (one per chunk, two steps ahead) take over.  A 65 536-frame batch spans 165 chunks.
+    // LDPC_AMD_CHUNK_BLOCKS: experiments / tests of the chunk edges.
+    chunk_blocks_ = 1120;
     if (const char *e = std::getenv("LDPC_AMD_CHUNK_BLOCKS"))
     {
         const long v = std::strtol(e, nullptr, 10);
@@ -649,6 +651,7 @@ void Engine::upload_plan()
         const FusedPlan &f = fused_plan_;
         dev_fused_.n_slots = f.n_slots, dev_fused_.vnb = f.vnb, dev_fused_.cnl = f.cnl, dev_fused_.calls_stride = f.calls_stride;
         dev_fused_.has_shortened = f.has_shortened ? 1 : 0;
+        dev_fused_.wide_exclusive = f.wide_exclusive ? 1 : 0;
         std::memcpy(dev_fused_.vn_prog, f.vn_prog, sizeof f.vn_prog);
         // the message slots; the prologue stages one 16-byte entry per transmitted bit or column (+ 2) in the same space
         dev_fused_.lds_bytes = static_cast<uint32_t>(std::max<size_t>(8 * static_cast<size_t>(f.n_slots), 16 * (static_cast<size_t>(std::max(p.nc, p.nct)) + 2)) + 15) & ~15u;
@@ -677,7 +680,7 @@ void Engine::synchronize(void *stream)
 uint64_t Engine::max_sub_batch() const
 {
     // the normals of a batch: at most kMaxSlabs chunk slabs (4 GB) per buffer
-    constexpr uint64_t kMaxSlabs = 476;
+    const uint64_t kMaxSlabs = std::max<uint64_t>(4, 476ull * 2240 / noise_.st.chunk_blocks());
     const uint64_t pairs_per_frame = std::max<uint64_t>(1, (static_cast<uint64_t>(plan_.nct) + 1) / 2 + 1);
     const uint64_t by_noise = std::max<uint64_t>(1, (kMaxSlabs - 2) * noise_.st.chunk_trials() * 3 / 4 / pairs_per_frame);
     if (plan_.lds_ok || reg_plan_.ok)

@@ -132,6 +132,7 @@ struct DevFusedPlan
 {
     int n_slots, vnb, cnl, calls_stride;
     int has_shortened;
+    int wide_exclusive;
     uint32_t vn_prog[kDecodeWaves]; // plan.hpp, FusedPlan::vn_prog
     uint32_t lds_bytes;          // dynamic LDS per frame: the message slots, or the staging area of the prologue if larger
     const FusedCall *leaf_calls; // [kDecodeWaves][kFusedLeafCalls]

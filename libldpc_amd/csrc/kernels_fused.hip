@@ -33,7 +33,7 @@
 #define LDPC_AMD_DECODE_PRIO 3
 #endif
 #ifndef LDPC_AMD_FUSED_WAVES
-#define LDPC_AMD_FUSED_WAVES 5
+#define LDPC_AMD_FUSED_WAVES 6
 #endif
 
 namespace ldpc_amd
@@ -165,7 +165,7 @@ __device__ __forceinline__ void vn2_one(char *msg, uint32_t packed_a, double ra,
 // degree DV in 3..15, slot offsets in registers (16 bits each, two per word): the wave's first block.  lambda(total) =
 // lambda_ch prod lambda(c2v_p) in column file order (decoder.cpp:50-56), range-checked at every third factor when the
 // product is longer than four; rho(v2c_p) = lambda(c2v_p) / lambda(total).  Returns lambda(total).
-template <int DV>
+template <int DV, bool TWICE>
 __device__ __forceinline__ double vn_wide(char *msg, const uint32_t (&packed)[8], double lam, Track &t, uint32_t &sg)
 {
     uint32_t pk[(DV + 1) / 2];
@@ -180,6 +180,12 @@ __device__ __forceinline__ double vn_wide(char *msg, const uint32_t (&packed)[8]
 #pragma unroll
     for (int p = 0; p < DV; ++p)
         c[p] = __builtin_fabs(*slot(p));
+    if constexpr (TWICE) // the offsets are unpacked again for the writes: fifteen addresses held across the product and the
+    {                    // division are fifteen registers the instantiation at six waves per SIMD does not have
+#pragma unroll
+        for (int i = 0; i < (DV + 1) / 2; ++i)
+            asm volatile("" : "+v"(pk[i]));
+    }
     double prod = lam;
 #pragma unroll
     for (int p = 0; p < DV; ++p)
@@ -214,12 +220,14 @@ __device__ __forceinline__ double vn_wide(char *msg, const uint32_t (&packed)[8]
 
 // any degree >= 3 through the plan's table of slot offsets (rolled: every message is read twice; blocks that are neither
 // the wave's first nor of degree 2 — none in the n = 1024 code)
-__device__ __forceinline__ double vn_table(char *msg, const uint32_t *idx, int count, int degree, double lam, Track &t, uint32_t &sg)
+__device__ __forceinline__ double vn_table(char *msg, const uint32_t *tbl, int lane, int count, int degree, double lam, Track &t, uint32_t &sg)
 {
+    // (tbl is wave-uniform, the lane joins as a 32-bit offset in every load: a per-lane pointer would be hoisted out of the
+    // decode loop and held — or spilled — for the whole decode)
     double prod = lam;
     for (int p = 0; p < degree; ++p)
     {
-        prod *= __builtin_fabs(*at(msg, idx[p * count]));
+        prod *= __builtin_fabs(*at(msg, tbl[p * count + lane]));
         if (degree > 3 && p % 3 == 2)
             track(t, prod);
     }
@@ -227,7 +235,7 @@ __device__ __forceinline__ double vn_table(char *msg, const uint32_t *idx, int c
     const double tot = dm_ratio_div(1.0, prod);
     for (int p = 0; p < degree; ++p)
     {
-        double *m = at(msg, idx[p * count]);
+        double *m = at(msg, tbl[p * count + lane]);
         const double o = tot * __builtin_fabs(*m);
         track(t, o);
         *m = with_sign(o, sg);
@@ -288,7 +296,7 @@ __device__ __forceinline__ AwgnFrame awgn_frame(const DecodeArgs &a, uint64_t fr
 }
 
 // =======================================================================================================================
-template <bool WANT_LLR, int VNB, int CNL>
+template <bool WANT_LLR, int VNB, int CNL, bool EXCL>
 __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPlan &F)
 {
     extern __shared__ double lds[];
@@ -392,14 +400,32 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
     const uint32_t vn_prog = F.vn_prog[wave];
     auto vn_cnt = [&](int w) { return my_vdesc[4 * w] & 0xFFFFu; };
     auto vn_deg = [&](int w) { return my_vdesc[4 * w] >> 16; };
+    // EXCL (the small instantiation; plan: FusedPlan::wide_exclusive): a wave either serves ONE block through register-held
+    // slot offsets (degree 3..15, slot 0) or blocks of degree 2, never both — the same eight registers m[] hold the wide
+    // block's sixteen offsets or the four packed offset words and two of the four channel ratios (twelve registers for the
+    // variable-node state instead of twenty: what six waves per SIMD need)
+    static_assert(!EXCL || VNB == 4, "the shared layout is written for four slots");
+    const bool is_wide = (vn_prog & 0xFu) == kFusedVnWide; // (wave-uniform)
     uint32_t my_idx[VNB + 1], wide_idx[8], vn_entry[VNB], leaf_entry[2 * CNL];
+    if constexpr (EXCL)
+    {
 #pragma unroll
-    for (int w = 0; w < VNB; ++w)
-        my_idx[w] = tab[w * kWaveSize];
+        for (int i = 0; i < 4; ++i)
+            wide_idx[i] = tab[((is_wide ? 8 : 0) + i) * kWaveSize];
+#pragma unroll
+        for (int i = 4; i < 8; ++i)
+            wide_idx[i] = tab[(8 + i) * kWaveSize];
+    }
+    else
+    {
+#pragma unroll
+        for (int w = 0; w < VNB; ++w)
+            my_idx[w] = tab[w * kWaveSize];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            wide_idx[i] = tab[(8 + i) * kWaveSize];
+    }
     my_idx[VNB] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        wide_idx[i] = tab[(8 + i) * kWaveSize];
     const uint32_t none_entry = static_cast<uint32_t>(n_stage + 1) * 16u;
 #pragma unroll
     for (int w = 0; w < VNB; ++w)
@@ -441,6 +467,7 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
     for (int c = 0; c < 2 * CNL; ++c)
         leaf_rho[c] = reinterpret_cast<const double2 *>(msg + leaf_entry[c])->y;
     __syncthreads();
+    auto idx_at = [&](int w) { return EXCL ? wide_idx[w] : my_idx[w]; };
 #pragma unroll
     for (int w = 0; w < VNB; ++w)
     {
@@ -449,8 +476,8 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
             continue;
         if (deg == 2)
         {
-            *at(msg, my_idx[w] & 0xFFFFu) = first_v2c[w];
-            *at(msg, my_idx[w] >> 16) = first_v2c[w];
+            *at(msg, idx_at(w) & 0xFFFFu) = first_v2c[w];
+            *at(msg, idx_at(w) >> 16) = first_v2c[w];
         }
         else if (w == 0 && deg <= 15)
         {
@@ -466,6 +493,22 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
                 *at(msg, idx[p * cnt]) = first_v2c[w];
         }
     }
+    if constexpr (EXCL)
+        if (!is_wide)
+        {
+            wide_idx[4] = static_cast<uint32_t>(dm_bits(my_val[1])), wide_idx[5] = hi_word(my_val[1]);
+            wide_idx[6] = static_cast<uint32_t>(dm_bits(my_val[2])), wide_idx[7] = hi_word(my_val[2]);
+        }
+    auto val_at = [&](int w) {
+        if constexpr (EXCL)
+        {
+            if (w == 1)
+                return dm_from_bits(wide_idx[4] | (static_cast<uint64_t>(wide_idx[5]) << 32));
+            if (w == 2)
+                return dm_from_bits(wide_idx[6] | (static_cast<uint64_t>(wide_idx[7]) << 32));
+        }
+        return my_val[w];
+    };
     __syncthreads();
 
     const auto my_leaf_calls = uniform_table(reinterpret_cast<const uint32_t *>(F.leaf_calls + wave * kFusedLeafCalls));
@@ -614,7 +657,7 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
             if (kind == kFusedVnPair || kind == kFusedVn2)
             {
                 double tt;
-                vn2_one(msg, my_idx[w], my_val[w], t, sg, tt);
+                vn2_one(msg, idx_at(w), val_at(w), t, sg, tt);
                 put_llr(w, dm_log(tt));
             }
             else
@@ -624,14 +667,14 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
                     switch (deg) // wave-uniform
                     {
 #define LDPC_VN(DV) \
-    case DV: prod = vn_wide<DV>(msg, wide_idx, my_val[0], t, sg); break;
+    case DV: prod = vn_wide<DV, EXCL>(msg, wide_idx, my_val[0], t, sg); break;
                         LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8) LDPC_VN(9)
                         LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15)
 #undef LDPC_VN
                     default: sg = 0; break;
                     }
                 else
-                    prod = vn_table(msg, F.vn_slot + vdesc_now[4 * w + 1] + lane, cnt, deg, my_val[w], t, sg);
+                    prod = vn_table(msg, F.vn_slot + vdesc_now[4 * w + 1], lane, cnt, deg, val_at(w), t, sg);
                 put_llr(w, 0.0 - dm_log(prod));
             }
             note(w, sg);
@@ -644,7 +687,7 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
             {
                 uint32_t sga, sgb;
                 double ta, tb;
-                vn2_pair(msg, my_idx[w], my_idx[w + 1], my_val[w], my_val[w + 1], t, sga, sgb, ta, tb);
+                vn2_pair(msg, idx_at(w), idx_at(w + 1), val_at(w), val_at(w + 1), t, sga, sgb, ta, tb);
                 note(w, sga), note(w + 1, sgb);
                 put_llr(w, dm_log(ta)), put_llr(w + 1, dm_log(tb));
             }
@@ -668,6 +711,10 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
     int err = 0;
     if (hard || a.bit_errors)
     {
+        // (the lane's row of the table is addressed afresh: held since the prologue the pointer costs the loop two registers)
+        int lane_now = lane;
+        asm volatile("" : "+v"(lane_now));
+        const uint32_t *tab = F.lane_tab + (static_cast<uint32_t>(wave) * kFusedLaneRows) * kWaveSize + lane_now;
         auto account = [&](uint32_t cwd, uint32_t bit) {
             if (cwd == kFusedNone)
                 return;
@@ -700,13 +747,13 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(LDPC_AMD_FUSED_WAVES, LDPC_AMD_FUSED_WAVES))) void
 decode_fused_small(const DecodeArgs a, const DevFusedPlan f)
 {
-    fused_body<false, 4, 1>(a, f);
+    fused_body<false, 4, 1, true>(a, f);
 }
 
 template <bool WANT_LLR, int VNB, int CNL>
 __global__ __launch_bounds__(kThreads) void decode_fused_kernel(const DecodeArgs a, const DevFusedPlan f)
 {
-    fused_body<WANT_LLR, VNB, CNL>(a, f);
+    fused_body<WANT_LLR, VNB, CNL, false>(a, f);
 }
 
 } // namespace
@@ -722,7 +769,7 @@ int launch_decode_fused(const DecodeArgs &a, const DevFusedPlan &f, void *stream
     const bool want_llr = a.llr_out != nullptr;
     void (*k)(const DecodeArgs, const DevFusedPlan) = nullptr;
     if (f.vnb <= 4 && f.cnl <= 1)
-        k = want_llr ? decode_fused_kernel<true, 4, 1> : decode_fused_small;
+        k = (want_llr || !f.wide_exclusive) ? (want_llr ? decode_fused_kernel<true, 4, 1> : decode_fused_kernel<false, 4, 1>) : decode_fused_small;
     else
         k = want_llr ? decode_fused_kernel<true, kFusedVnSlots, kFusedLeafCalls> : decode_fused_kernel<false, kFusedVnSlots, kFusedLeafCalls>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(f.lds_bytes));

@@ -742,6 +742,10 @@ FusedPlan build_fused_plan(const LdpcCode &code, const Plan &plan)
     }
     if (f.vn_slot.empty())
         f.vn_slot.push_back(0);
+    f.wide_exclusive = true;
+    for (int w = 0; w < W; ++w)
+        if ((f.vn_prog[w] & 0xFu) == kFusedVnWide && (f.vn_prog[w] >> 4) != 0)
+            f.wide_exclusive = false;
     f.ok = true;
     return f;
 }

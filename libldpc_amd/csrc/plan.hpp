@@ -209,6 +209,7 @@ struct FusedPlan
     int n_slots = 0;     // message slots
     int vnb = 0, cnl = 0; // largest number of variable-node blocks / of leaf calls any wave holds
     bool has_shortened = false;
+    bool wide_exclusive = false; // a wave that serves a block through register-held offsets (slot 0, degree 3..15) serves no other
     std::vector<FusedCall> leaf_calls; // [kDecodeWaves][kFusedLeafCalls]
     std::vector<FusedCall> calls;      // [kDecodeWaves][calls_stride], each row ends in a zero entry
     int calls_stride = 0;

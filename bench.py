@@ -60,7 +60,7 @@ MIX_PASS = ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA
 # ------------------------------------------------------------------------------------------------------------
 # legs that run in child processes before this process touches the GPU
 # ------------------------------------------------------------------------------------------------------------
-def pmc_passes(cfg, batch, steps=2, warmup=1):
+def pmc_passes(cfg, batch, steps=2, warmup=1, passes=("sq", "mix", "fetch", "write")):
     """Per-launch counter averages of the dominant decode kernel of this workload: three separate rocprofv3 --pmc
     passes (SQ set; FETCH_SIZE; WRITE_SIZE — MI355X_MICROARCH.md §rocprofv3 PMC slots) of tools/pmc_probe.py.
     Returns None when rocprofv3 is not usable here."""
@@ -76,6 +76,8 @@ def pmc_passes(cfg, batch, steps=2, warmup=1):
     agg, meta = {}, {}
     try:
         for name, counters in (("sq", SQ_PASS), ("mix", MIX_PASS), ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+            if name not in passes:
+                continue
             out = os.path.join(tmp, name)
             p = subprocess.run([rocprof, "--pmc", *counters, "-d", out, "-o", "run", "--output-format", "csv", "--", *probe],
                                cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
@@ -134,7 +136,8 @@ def roofline_from(pmc, kernel_ms, eu_per_launch, w):
     valu_busy = c["SQ_ACTIVE_INST_VALU"] * 4.0          # quad-cycles -> SIMD-cycles in which a VALU instruction executes
     valu_issue = c["SQ_INSTS_VALU"] * 4.0               # wave-instructions x 4 cycles (16 fp64 lanes/clk/SIMD)
     lds_busy = c["SQ_LDS_IDX_ACTIVE"]                   # LDS-array cycles, conflicts included
-    hbm_bytes = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0  # gfx950: FETCH_SIZE counts 128-B requests at 64 B
+    # gfx950: FETCH_SIZE counts 128-B requests at 64 B (None: the byte passes were not run, other_configs)
+    hbm_bytes = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
     ceilings = {
         "valu": {"achieved": valu_busy / t / 1e9, "peak": N_SIMD * CLOCK_HZ / 1e9, "unit": "G SIMD-busy-cycles/s",
                  "busy_frac_of_kernel_cycles": valu_busy / (N_SIMD * cycles), "issue_frac_of_kernel_cycles": valu_issue / (N_SIMD * cycles),
@@ -143,8 +146,9 @@ def roofline_from(pmc, kernel_ms, eu_per_launch, w):
         "lds": {"achieved": lds_busy / t / 1e9, "peak": N_CU * CLOCK_HZ / 1e9, "unit": "G LDS-array-cycles/s",
                 "busy_frac_of_kernel_cycles": lds_busy / (N_CU * cycles), "bank_conflict_frac": c["SQ_LDS_BANK_CONFLICT"] / max(lds_busy, 1.0),
                 "lds_wave_instructions_per_launch": c["SQ_INSTS_LDS"]},
-        "hbm": {"achieved": hbm_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"},
     }
+    if hbm_bytes is not None:
+        ceilings["hbm"] = {"achieved": hbm_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
     for v in ceilings.values():
         v["frac"] = v["achieved"] / v["peak"]
     eu = max(pmc.get("probe", {}).get("edge_updates", 0) / max(pmc.get("probe", {}).get("steps", 1), 1), 1)
@@ -182,7 +186,6 @@ def cpu_baseline(w, budget_s=18.0):
     cores = os.cpu_count() or 1
     ref = os.path.join(ROOT, "oracle", "_ref", "ldpcsim_ref")
     d = workloads.code_dims(w)
-    guess = {"1": 700, "2": 700, "2f": 700, "2l": 700, "2h": 700, "2n": 230, "3": 1100, "4": 90, "4n": 13, "5": 500, "5bec": 4300}[w["key"]]  # frames/s, one core
     out = os.path.join(tempfile.gettempdir(), f"ldpc_ref_{os.getpid()}.txt")
 
     def run_ref(frames, threads):
@@ -198,7 +201,8 @@ def cpu_baseline(w, budget_s=18.0):
         return frames / dt, dt, frames, avg_it
 
     if os.path.exists(ref):
-        r1, dt1, n1, _ = run_ref(max(8, int(guess * 4)), 1)
+        r0, _, _, _ = run_ref(8, 1)                        # calibration: eight frames on one thread (a fraction of a second)
+        r1, dt1, n1, _ = run_ref(max(8, int(r0 * 3.0)), 1)  # one thread, about three seconds
         # the reference's shared counters (omp atomic/critical, ldpcsim.cpp:175-252) stop scaling at about eight threads'
         # worth of work (measured on the 256-core GPU box): size the all-core sample for that
         rN, dtN, nN, avg_it = run_ref(max(64, int(r1 * min(cores, 8) * budget_s)), cores)
@@ -212,6 +216,10 @@ def cpu_baseline(w, budget_s=18.0):
                           f"on {cores} threads; one thread: {n1} frames in {dt1:.1f}s"}
     import orc  # the C restatement, OpenMP over frames (checked bit for bit against the reference in tests/test_oracle_golden.py)
     code = orc.Code(workloads.code_path(w))
+    t0 = time.time()
+    code.simulate(w["channel"], [w["x"], w["x"] + 1e-4, 1], threads=1, max_frames=8, min_fec=10**9, iters=w["iterations"],
+                  early_term=w["early_term"], min_sum=w["decoding"] == "BP_MS")  # calibration: eight frames on one thread
+    guess = 8 / max(time.time() - t0, 1e-3)
     frames = max(64, int(guess * min(cores, 32) * budget_s * 0.5))
     t0 = time.time()
     res = code.simulate(w["channel"], [w["x"], w["x"] + 1e-4, 1], threads=cores, max_frames=frames, min_fec=10**9,
@@ -220,6 +228,42 @@ def cpu_baseline(w, budget_s=18.0):
     n_frames, _, _, it = (int(v) for v in res["totals"][0])
     return {"value": n_frames / dt, "unit": "frames/s", "edge_updates_per_s": (it + n_frames) * d["nnz"] / dt, "cores": cores,
             "kind": "port", "sample": f"oracle port, {cores} OpenMP threads, {n_frames} frames, wall {dt:.1f}s"}
+
+
+def other_configs(budget_s=75.0):
+    """The other BASELINE.json configurations under the same clock as the headline: each a short child run
+    of this script (its own process, before this one touches the GPU): value, ms_per_step, kernel_ms_avg, edge-updates/s
+    and roofline bound / frac (counter passes for configuration 4 only: the instruction mix of the register-resident
+    kernel; the others report the on-chip ceiling without a fraction).  Keys: BASELINE.json configs[0], [2], [3], [4]
+    (BSC and BEC)."""
+    t0 = time.time()
+    out = {}
+    plan = [("1", ["--steps", "400", "--warmup", "50"], False), ("3", ["--steps", "10", "--warmup", "3"], False),
+            ("4", ["--steps", "10", "--warmup", "3"], True), ("5", ["--steps", "10", "--warmup", "3"], False),
+            ("5bec", ["--steps", "10", "--warmup", "3"], False)]
+    env = dict(os.environ, LDPC_BENCH_OTHER="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LDPC_BENCH_CHILD"):
+        env.pop(k, None)
+    for key, extra, with_mix in plan:
+        if time.time() - t0 > budget_s:
+            out[key] = {"error": "skipped: time budget of the default run spent"}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", key, "--no-cpu-baseline", "--no-other-configs", *extra]
+        cmd.append("--pmc-passes=sq,mix" if with_mix else "--no-pmc")
+        try:
+            p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+            j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+            r = j.get("roofline") or {}
+            out[key] = {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                        "steps": j["steps"], "kernel_ms_avg": r.get("kernel_ms_avg"), "edge_updates_per_s": j.get("edge_updates_per_s"),
+                        "roofline": {"bound": r.get("bound"), "frac": r.get("frac"), "valu_busy": r.get("valu_busy")},
+                        "dtype": j["dtype"]}
+            if "latency_us" in j:
+                out[key]["latency_us"] = j["latency_us"]
+        except Exception as e:  # (a failing side measurement must not take the headline line down)
+            out[key] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    out["seconds"] = time.time() - t0
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -352,6 +396,8 @@ def run_rank(args, w):
     tot.zero_()
     span[0] = None
     own.clear()
+    if comm is not None:
+        comm.exchange_stats(reset=True)  # (host time inside the all-gathers: the timed steps only)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]  # per-step spread without a host sync per step
     if dist is not None:
         dist.barrier()
@@ -362,6 +408,8 @@ def run_rank(args, w):
         step()
         marks[k + 1].record()
     torch.cuda.synchronize()
+    exch = comm.exchange_stats() if comm is not None else {"calls": 0, "min": 0.0, "median": 0.0, "max": 0.0}
+    transport = comm.describe() if comm is not None else "none (one rank)"
     if comm is not None:  # the one reduce of the counters: 5 x int64 per rank through the library's communicator
         tot = torch.from_numpy(comm.all_gather(tot.cpu().numpy().astype("uint64")).astype("int64").sum(axis=0))
     if dist is not None:
@@ -377,7 +425,9 @@ def run_rank(args, w):
             "host_wait_noise_ms_avg": wait_ms, "comm_init_s": comm_init_s, "frames": int(sum(own)),
             "frames_per_step_min": int(min(own)), "frames_per_step_max": int(max(own)),
             "step_ms": {"min": step_ms[0], "median": step_ms[len(step_ms) // 2], "max": step_ms[-1]},
-            "jump_tasks": int(dec.jump_tasks)}
+            "jump_tasks": int(dec.jump_tasks),
+            # host microseconds inside Comm::all_gather per timed step (copy in, ncclAllGather, copy out, bounded wait)
+            "exchange_us": {"min": exch["min"], "median": exch["median"], "max": exch["max"]}, "transport": transport}
     per_rank = [mine]
     t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist is not None:
@@ -402,6 +452,9 @@ def run_rank(args, w):
              "frames_per_step": {"min": min(r["frames_per_step_min"] for r in per_rank), "max": max(r["frames_per_step_max"] for r in per_rank)},
              "step_ms": {"min": min(r["step_ms"]["min"] for r in per_rank), "median_max_over_ranks": max(r["step_ms"]["median"] for r in per_rank),
                          "max": max(r["step_ms"]["max"] for r in per_rank)},
+             "exchange_us": {"min": min(r["exchange_us"]["min"] for r in per_rank), "median_max_over_ranks": max(r["exchange_us"]["median"] for r in per_rank),
+                             "max": max(r["exchange_us"]["max"] for r in per_rank)},
+             "transport": per_rank[0]["transport"],
              "per_rank": per_rank}
     return ({"frames": frames, "dt": dt, "edge_updates": edge_updates, "kernel_ms": max(r["kernel_ms_avg"] for r in per_rank),
              "extra": {"fer": fec / frames, "ber": bec / (frames * d["nc"]), "avg_iter": it_sum / frames, "rng_ms_avg": rng_ms,
@@ -430,6 +483,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU and step (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline fields become null)")
+    ap.add_argument("--pmc-passes", default="sq,mix,fetch,write", help="which counter passes to run (comma-separated)")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run only: skip the short runs of the other BASELINE configurations")
     args = ap.parse_args()
     w = workloads.get(args.config)
     if args.steps is None:
@@ -451,9 +506,11 @@ def main():
     legs = {}
     if leader and args.gpus == 1:
         if not args.no_pmc and args.config != "1":
-            legs["pmc"] = pmc_passes(args.config, args.batch or w["batch"])
+            legs["pmc"] = pmc_passes(args.config, args.batch or w["batch"], passes=tuple(args.pmc_passes.split(",")))
         if not args.no_cpu_baseline:
             legs["cpu"] = cpu_baseline(w)
+        if args.config == "2" and not args.no_other_configs and not args.batch:
+            legs["other"] = other_configs()
 
     if world_env is None and args.gpus > 1:
         # plain `python bench.py --gpus N`: one fresh process per GPU; this parent never initialises the GPU
@@ -516,6 +573,8 @@ def finish(res, legs, w):
         res["roofline"] = roofline_from(legs.get("pmc"), kernel_ms, eu, w)
     if "cpu" in legs:
         res["cpu_baseline"] = legs["cpu"]
+    if "other" in legs:
+        res["other_configs"] = legs["other"]
 
 
 if __name__ == "__main__":

@@ -211,8 +211,20 @@ ldpc_hip_comm *ldpc_hip_comm_create_shm(int rank, int world, const char *name);
    caller's own payload.  For cost probes of the sharded step on one GPU (tools/shard_probe.py), not for results. */
 ldpc_hip_comm *ldpc_hip_comm_create_echo(int rank, int world);
 void ldpc_hip_comm_destroy(ldpc_hip_comm *comm);
-/* recv[q*bytes ..) = rank q's send[0 .. bytes): host buffers, bytes a multiple of 8 and at most 256 */
+/* recv[q*bytes ..) = rank q's send[0 .. bytes): host buffers, bytes a multiple of 8 and at most 256.  Never waits without a
+   bound: when a rank does not arrive within LDPC_AMD_COMM_TIMEOUT_S seconds (default 60; ncclCommInitRank in
+   ldpc_hip_comm_create likewise) the call fails on the ranks that wait for it and the communicator is unusable from then on */
 int ldpc_hip_comm_allgather(ldpc_hip_comm *comm, const void *send, void *recv, uint64_t bytes);
+/* the placement step of ldpc_hip_stream_decode_sharded by itself, without a GPU (tests): this rank reports {pairs in its
+   piece, pairs including the margin, status}; after the all-gather over `comm` out = {first frame, frames of this rank,
+   frames of the step, stream index of the piece's first pair, stream index of the first pair after the step}.  A non-zero
+   status on any rank, a piece with more frames than cap, or a frame beyond a margin fails the call on every rank. */
+int ldpc_hip_selftest_place(ldpc_hip_comm *comm, uint64_t nct, uint64_t pairs_before, uint64_t frame_pos, uint64_t cap,
+                            uint64_t piece_pairs, uint64_t pairs_with_margin, uint64_t status, uint64_t out[5]);
+/* host microseconds spent inside the communicator's all-gathers since the last reset: out = {calls, min, median, max} */
+void ldpc_hip_comm_stats(ldpc_hip_comm *comm, double out[4], int reset);
+/* "rccl 2.22.3", "shm" or "echo" (valid until the communicator is destroyed) */
+const char *ldpc_hip_comm_describe(ldpc_hip_comm *comm);
 
 /* frames the output buffers of ldpc_hip_stream_decode_sharded must hold for a step of target_frames frames: a bound (every
    trial of a piece accepted), not a statistical estimate */

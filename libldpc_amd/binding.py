@@ -91,6 +91,12 @@ def load_library(path=LIB_PATH):
     L.ldpc_hip_comm_destroy.argtypes = [vp]
     L.ldpc_hip_comm_allgather.restype = i32
     L.ldpc_hip_comm_allgather.argtypes = [vp, vp, vp, u64]
+    L.ldpc_hip_selftest_place.restype = i32
+    L.ldpc_hip_selftest_place.argtypes = [vp, u64, u64, u64, u64, u64, u64, u64, vp]
+    L.ldpc_hip_comm_stats.restype = None
+    L.ldpc_hip_comm_stats.argtypes = [vp, vp, i32]
+    L.ldpc_hip_comm_describe.restype = ct.c_char_p
+    L.ldpc_hip_comm_describe.argtypes = [vp]
     L.ldpc_hip_shard_capacity.restype = u64
     L.ldpc_hip_shard_capacity.argtypes = [vp, u64, i32]
     L.ldpc_hip_stream_decode_sharded.restype = i32
@@ -163,6 +169,23 @@ class Comm:
         if self.lib.ldpc_hip_comm_allgather(self.handle, v.ctypes.data, out.ctypes.data, v.nbytes) != 0:
             raise RuntimeError("ldpc_hip_comm_allgather: " + self.lib.ldpc_hip_last_error().decode())
         return out
+
+    def place(self, nct, pairs_before, frame_pos, cap, piece_pairs, pairs_with_margin, status=0):
+        """The placement step of a sharded AWGN step over this communicator (no GPU): (first frame, frames of this rank,
+        frames of the step, first pair of the piece, first pair after the step)."""
+        out = (ct.c_uint64 * 5)()
+        if self.lib.ldpc_hip_selftest_place(self.handle, nct, pairs_before, frame_pos, cap, piece_pairs, pairs_with_margin, status, out) != 0:
+            raise RuntimeError("ldpc_hip_selftest_place: " + self.lib.ldpc_hip_last_error().decode())
+        return tuple(int(v) for v in out)
+
+    def exchange_stats(self, reset=False):
+        """host microseconds inside the all-gathers since the last reset: {"calls", "min", "median", "max"}"""
+        out = (ct.c_double * 4)()
+        self.lib.ldpc_hip_comm_stats(self.handle, out, int(reset))
+        return {"calls": int(out[0]), "min": out[1], "median": out[2], "max": out[3]}
+
+    def describe(self):
+        return self.lib.ldpc_hip_comm_describe(self.handle).decode()
 
     def close(self):
         if getattr(self, "handle", None):

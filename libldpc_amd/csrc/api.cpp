@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "engine.hpp"
+#include "shard_place.hpp"
 #include "sim.hpp"
 
 using namespace ldpc_amd;
@@ -23,6 +24,7 @@ using namespace ldpc_amd;
 struct ldpc_hip_comm
 {
     std::unique_ptr<Comm> comm;
+    std::string description;
 };
 
 struct ldpc_hip_ctx
@@ -566,6 +568,27 @@ void ldpc_hip_comm_destroy(ldpc_hip_comm *comm) { delete comm; }
 int ldpc_hip_comm_allgather(ldpc_hip_comm *comm, const void *send, void *recv, uint64_t bytes)
 {
     return guarded([&] { comm->comm->all_gather(send, recv, bytes); });
+}
+
+int ldpc_hip_selftest_place(ldpc_hip_comm *comm, uint64_t nct, uint64_t pairs_before, uint64_t frame_pos, uint64_t cap,
+                            uint64_t piece_pairs, uint64_t pairs_with_margin, uint64_t status, uint64_t out[5])
+{
+    return guarded([&] {
+        const int R = comm->comm->world(), r = comm->comm->rank();
+        const uint64_t send[3] = {piece_pairs, pairs_with_margin, status};
+        std::vector<uint64_t> all(3 * static_cast<size_t>(R));
+        comm->comm->all_gather(send, all.data(), sizeof send);
+        const ShardPlacement pl = place_pieces(all.data(), R, r, pairs_before, frame_pos, nct, cap, status ? "status word set by the caller" : "");
+        out[0] = pl.first, out[1] = pl.n, out[2] = pl.step_frames, out[3] = pl.pair_start, out[4] = pl.pairs_after;
+    });
+}
+
+void ldpc_hip_comm_stats(ldpc_hip_comm *comm, double out[4], int reset) { comm->comm->exchange_stats(out, reset != 0); }
+
+const char *ldpc_hip_comm_describe(ldpc_hip_comm *comm)
+{
+    comm->description = comm->comm->describe();
+    return comm->description.c_str();
 }
 
 uint64_t ldpc_hip_shard_capacity(const ldpc_hip_ctx *ctx, uint64_t target_frames, int world) { return ctx->eng->shard_capacity(target_frames, world < 1 ? 1 : world); }

@@ -9,14 +9,50 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 
 namespace ldpc_amd
 {
+
+void Comm::all_gather(const void *send, void *recv, size_t bytes)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    exchange(send, recv, bytes);
+    const float us = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (exchange_us_.size() < (1u << 20))
+        exchange_us_.push_back(us);
+}
+
+void Comm::exchange_stats(double out[4], bool reset)
+{
+    std::vector<float> v = exchange_us_;
+    std::sort(v.begin(), v.end());
+    out[0] = static_cast<double>(v.size());
+    out[1] = v.empty() ? 0.0 : v.front();
+    out[2] = v.empty() ? 0.0 : v[v.size() / 2];
+    out[3] = v.empty() ? 0.0 : v.back();
+    if (reset)
+        exchange_us_.clear();
+}
+
+double Comm::timeout_seconds(double fallback)
+{
+    if (const char *e = std::getenv("LDPC_AMD_COMM_TIMEOUT_S"))
+    {
+        const double v = std::strtod(e, nullptr);
+        if (v > 0)
+            return v;
+    }
+    return fallback;
+}
 
 void Comm::all_reduce_sum(int64_t *values, size_t n)
 {
@@ -50,6 +86,8 @@ struct Rccl
     int (*GetUniqueId)(UniqueId *) = nullptr;
     int (*CommInitRank)(comm_t *, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(comm_t) = nullptr;
+    int (*CommAbort)(comm_t) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, comm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 
@@ -73,6 +111,8 @@ struct Rccl
             r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
             r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
             r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+            r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(h, "ncclCommAbort"));
+            r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(h, "ncclGetVersion"));
             r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         }
         return r;
@@ -93,30 +133,77 @@ void hip_check(hipError_t e, const char *what)
 class RcclComm final : public Comm
 {
   public:
+    // ncclCommInitRank is a collective: it returns when every rank of the world has called it.  It runs on a thread of its
+    // own so that a rank whose peers never arrive (a process that died before the rendezvous) gives up after the deadline
+    // instead of blocking for ever: the constructor throws, the caller exits non-zero, the launcher ends the job.  (The
+    // thread itself cannot be cancelled; it is left behind in a process that is about to end.)
     RcclComm(int rank, int world, int device, const uint8_t *id) : device_(device)
     {
         rank_ = rank, world_ = world;
         Rccl &r = Rccl::get();
         hip_check(hipSetDevice(device_), "hipSetDevice");
+        struct Init
+        {
+            std::mutex m;
+            std::condition_variable cv;
+            bool done = false;
+            int rc = 0;
+            Rccl::comm_t comm = nullptr;
+        };
+        auto st = std::make_shared<Init>();
         Rccl::UniqueId uid;
         std::memcpy(uid.internal, id, kCommIdBytes);
-        r.check(r.CommInitRank(&comm_, world, uid, rank), "ncclCommInitRank");
+        std::thread([st, uid, world, rank, device, &r] {
+            Rccl::comm_t c = nullptr;
+            int rc = static_cast<int>(hipSetDevice(device));
+            if (rc == 0)
+                rc = r.CommInitRank(&c, world, uid, rank);
+            std::lock_guard<std::mutex> g(st->m);
+            st->rc = rc, st->comm = c, st->done = true;
+            st->cv.notify_all();
+        }).detach();
+        {
+            std::unique_lock<std::mutex> lk(st->m);
+            const double limit = timeout_seconds(60.0);
+            if (!st->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return st->done; }))
+                throw std::runtime_error("RCCL: ncclCommInitRank did not return within " + std::to_string(static_cast<int>(limit)) +
+                                         " s (rank " + std::to_string(rank) + " of " + std::to_string(world) +
+                                         "): a peer never reached the rendezvous (LDPC_AMD_COMM_TIMEOUT_S)");
+            r.check(st->rc, "ncclCommInitRank");
+            comm_ = st->comm;
+        }
         hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
         hip_check(hipMalloc(&dev_, kMaxBytes * static_cast<size_t>(world + 1)), "hipMalloc");
     }
     ~RcclComm() override
     {
-        if (comm_)
-            (void)Rccl::get().CommDestroy(comm_);
-        if (dev_)
+        if (comm_) // (a communicator whose collective timed out is aborted: ncclCommDestroy would wait for it)
+            (void)((broken_ && Rccl::get().CommAbort) ? Rccl::get().CommAbort(comm_) : Rccl::get().CommDestroy(comm_));
+        if (dev_ && !broken_)
             (void)hipFree(dev_);
-        if (stream_)
+        if (stream_ && !broken_)
             (void)hipStreamDestroy(stream_);
     }
-    void all_gather(const void *send, void *recv, size_t bytes) override
+    std::string describe() const override
+    {
+        int v = 0;
+        if (Rccl::get().GetVersion && Rccl::get().GetVersion(&v) == 0 && v > 0)
+        {
+            // NCCL_VERSION_CODE: major * 10000 + minor * 100 + patch from 2.9 on (major * 1000 + ... before)
+            const int major = v >= 20000 ? v / 10000 : v / 1000, minor = v >= 20000 ? (v / 100) % 100 : (v / 100) % 10, patch = v % 100;
+            return "rccl " + std::to_string(major) + "." + std::to_string(minor) + "." + std::to_string(patch);
+        }
+        return "rccl";
+    }
+    const char *transport() const override { return "rccl"; }
+
+  protected:
+    void exchange(const void *send, void *recv, size_t bytes) override
     {
         if (bytes == 0 || bytes > kMaxBytes || bytes % 8)
             throw std::runtime_error("RcclComm::all_gather: payload must be a multiple of 8 bytes, at most 256");
+        if (broken_)
+            throw std::runtime_error("RcclComm::all_gather: the communicator is unusable after a collective that timed out");
         Rccl &r = Rccl::get();
         hip_check(hipSetDevice(device_), "hipSetDevice");
         char *d = static_cast<char *>(dev_);
@@ -124,15 +211,35 @@ class RcclComm final : public Comm
         // the one collective of the path: world x bytes over xGMI, latency-bound
         r.check(r.AllGather(d, d + kMaxBytes, bytes / 8, /*ncclUint64*/ 5, comm_, stream_), "ncclAllGather");
         hip_check(hipMemcpyAsync(recv, d + kMaxBytes, bytes * static_cast<size_t>(world_), hipMemcpyDeviceToHost, stream_), "copy out");
-        hip_check(hipStreamSynchronize(stream_), "sync");
+        // bounded wait: a peer that died never joins the collective, and hipStreamSynchronize would wait for it for ever
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_seconds(60.0));
+        unsigned spins = 0;
+        for (;;)
+        {
+            const hipError_t q = hipStreamQuery(stream_);
+            if (q == hipSuccess)
+                return;
+            if (q != hipErrorNotReady)
+                hip_check(q, "all-gather stream");
+            if (++spins > 4000) // (the exchange normally completes within tens of microseconds: spin first, then yield)
+            {
+                if (std::chrono::steady_clock::now() > deadline)
+                {
+                    broken_ = true;
+                    throw std::runtime_error("RCCL: the all-gather did not complete within the deadline (rank " + std::to_string(rank_) + " of " +
+                                             std::to_string(world_) + "): a peer left the job (LDPC_AMD_COMM_TIMEOUT_S)");
+                }
+                std::this_thread::yield();
+            }
+        }
     }
-    const char *transport() const override { return "rccl"; }
 
   private:
     int device_;
     Rccl::comm_t comm_ = nullptr;
     hipStream_t stream_ = nullptr;
     void *dev_ = nullptr;
+    bool broken_ = false;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -142,6 +249,7 @@ struct ShmSeg
 {
     static constexpr int kMaxRanks = 64;
     static constexpr uint64_t kMagic = 0x6c6470635f616d64ull; // "ldpc_amd"
+    static constexpr uint32_t kSealed = 0x80000000u;          // in `attached`: rank 0 found every rank attached
     std::atomic<uint64_t> seq[kMaxRanks];
     std::atomic<uint64_t> magic; // set by rank 0 once the object is sized and zero-filled
     std::atomic<uint32_t> attached;
@@ -174,8 +282,15 @@ class ShmComm final : public Comm
             seg_ = map(fd); // a fresh object is zero-filled: every seq starts at 0
             seg_->magic.store(ShmSeg::kMagic, std::memory_order_release);
             seg_->attached.fetch_add(1);
-            while (seg_->attached.load() < static_cast<uint32_t>(world)) // everyone is in before the name goes away
+            // everyone is in before the name goes away.  The count is SEALED in the same atomic step that finds it complete:
+            // a rank whose patience runs out at that very moment (it lets go of objects that never get the go-ahead, below)
+            // either takes its attachment back before the seal — then the count is not complete and rank 0 keeps waiting for
+            // it to come back — or finds the seal and stays.
+            for (;;)
             {
+                uint32_t expect = static_cast<uint32_t>(world);
+                if (seg_->attached.compare_exchange_strong(expect, static_cast<uint32_t>(world) | ShmSeg::kSealed))
+                    break;
                 if (std::chrono::steady_clock::now() > deadline)
                 {
                     (void)shm_unlink(name.c_str());
@@ -220,15 +335,22 @@ class ShmComm final : public Comm
             }
             if (seg->magic.load(std::memory_order_acquire) == ShmSeg::kMagic)
             {
-                // take the attachment back — unless the go-ahead arrived in between (rank 0 counts attachments)
+                // take the attachment back — unless rank 0 has sealed the count in between: then this IS the job's object
+                // and the go-ahead follows at once
                 uint32_t cur = seg->attached.load();
-                while (seg->go.load(std::memory_order_acquire) == 0 && !seg->attached.compare_exchange_weak(cur, cur - 1))
+                bool sealed = false;
+                while (!(sealed = (cur & ShmSeg::kSealed) != 0) && !seg->attached.compare_exchange_weak(cur, cur - 1))
                 {
                 }
-                if (seg->go.load(std::memory_order_acquire) != 0)
+                if (sealed)
                 {
-                    seg_ = seg;
-                    return;
+                    while (seg->go.load(std::memory_order_acquire) == 0 && std::chrono::steady_clock::now() < deadline)
+                        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                    if (seg->go.load(std::memory_order_acquire) != 0)
+                    {
+                        seg_ = seg;
+                        return;
+                    }
                 }
             }
             munmap(seg, sizeof(ShmSeg));
@@ -240,14 +362,17 @@ class ShmComm final : public Comm
         if (seg_)
             munmap(seg_, sizeof(ShmSeg));
     }
-    void all_gather(const void *send, void *recv, size_t bytes) override
+    const char *transport() const override { return "shm"; }
+
+  protected:
+    void exchange(const void *send, void *recv, size_t bytes) override
     {
         if (bytes == 0 || bytes > kMaxBytes)
             throw std::runtime_error("ShmComm::all_gather: payload too large");
         const uint64_t k = calls_++;
         std::memcpy(seg_->data[k & 1][rank_], send, bytes);
         seg_->seq[rank_].store(k + 1, std::memory_order_release);
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(600);
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_seconds(600.0));
         for (int q = 0; q < world_; ++q)
         {
             unsigned spins = 0;
@@ -263,7 +388,6 @@ class ShmComm final : public Comm
         // slot k&1 is rewritten in call k+2, which a rank enters only after every rank has published call k+1,
         // i.e. after every rank has finished reading call k
     }
-    const char *transport() const override { return "shm"; }
 
   private:
     std::string name_;
@@ -279,14 +403,16 @@ class EchoComm final : public Comm
             throw std::runtime_error("EchoComm: bad rank / world size");
         rank_ = rank, world_ = world;
     }
-    void all_gather(const void *send, void *recv, size_t bytes) override
+    const char *transport() const override { return "echo"; }
+
+  protected:
+    void exchange(const void *send, void *recv, size_t bytes) override
     {
         if (bytes == 0 || bytes > kMaxBytes)
             throw std::runtime_error("EchoComm::all_gather: payload too large");
         for (int q = 0; q < world_; ++q)
             std::memcpy(static_cast<char *>(recv) + static_cast<size_t>(q) * bytes, send, bytes);
     }
-    const char *transport() const override { return "echo"; }
 };
 } // namespace
 

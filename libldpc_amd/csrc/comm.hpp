@@ -30,16 +30,27 @@ class Comm
     virtual ~Comm() = default;
     int rank() const { return rank_; }
     int world() const { return world_; }
-    // recv[q*bytes .. (q+1)*bytes) = rank q's send[0..bytes), host buffers, blocking; bytes <= kMaxBytes
-    virtual void all_gather(const void *send, void *recv, size_t bytes) = 0;
+    // recv[q*bytes .. (q+1)*bytes) = rank q's send[0..bytes), host buffers, blocking; bytes <= kMaxBytes.  Never waits
+    // without a bound: a rank that does not arrive within the deadline (LDPC_AMD_COMM_TIMEOUT_S, default 60 s; shared
+    // memory: 600 s) makes the call throw on every rank that waits for it.  The host time of every call is recorded.
+    void all_gather(const void *send, void *recv, size_t bytes);
     virtual const char *transport() const = 0;
+    // "rccl 2.22.3", "shm", "echo"
+    virtual std::string describe() const { return transport(); }
     static constexpr size_t kMaxBytes = 256;
+    // host microseconds inside all_gather since the last reset: {calls, min, median, max}
+    void exchange_stats(double out[4], bool reset);
+    static double timeout_seconds(double fallback);
 
     // sum of n int64 values over all ranks (an all-gather and a local sum: the payloads are a few words)
     void all_reduce_sum(int64_t *values, size_t n);
 
   protected:
+    virtual void exchange(const void *send, void *recv, size_t bytes) = 0;
     int rank_ = 0, world_ = 1;
+
+  private:
+    std::vector<float> exchange_us_;
 };
 
 // fills id[kCommIdBytes] with a fresh ncclUniqueId (rank 0 calls this, every rank gets the bytes)

@@ -1,5 +1,6 @@
 // engine.cpp — see engine.hpp.  Compiled by hipcc (host code using the HIP runtime API).
 #include "engine.hpp"
+#include "shard_place.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -1470,7 +1471,7 @@ void Engine::encoder_restore_and_skip(uint64_t frames, void *stream)
 }
 
 Engine::ShardStep Engine::stream_decode_sharded(Comm &comm, const DecParams &p, uint64_t target_frames, const BatchOut &out,
-                                                void *stream)
+                                                void *stream, const std::string *failed_before)
 {
     // (argument errors: the same on every rank, thrown before anything is exchanged)
     if (!chan_)
@@ -1481,7 +1482,7 @@ Engine::ShardStep Engine::stream_decode_sharded(Comm &comm, const DecParams &p, 
     if (stream_mode_ == 1)
         throw std::runtime_error("stream_decode_sharded after stream_decode on the same stream: call stream_begin first");
     stream_mode_ = 2;
-    if (chan_ != kAwgn)
+    if (chan_ != kAwgn && !failed_before)
         upload_plan();
     ShardStep st;
     st.step_first = frame_pos_;
@@ -1500,6 +1501,10 @@ Engine::ShardStep Engine::stream_decode_sharded(Comm &comm, const DecParams &p, 
         int buf = -1;
         try
         {
+            // (a caller whose own preparation failed on this rank — the simulation loop's encoder snapshot — still has to
+            // take part in the exchange below, or the other ranks wait in it for ever: it enters with the failure in hand)
+            if (failed_before)
+                throw std::runtime_error(*failed_before);
             if (cap > max_sub_batch())
                 throw std::runtime_error("sharded step too large for one launch per rank");
             upload_plan(); // (the first touch of the GPU: a rank without a usable device fails here, inside the guarded part)
@@ -1526,39 +1531,21 @@ Engine::ShardStep Engine::stream_decode_sharded(Comm &comm, const DecParams &p, 
         const auto t0 = std::chrono::steady_clock::now();
         comm.all_gather(send, all.data(), sizeof send);
         host_ms_[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ++host_n_[0];
-        for (int q = 0; q < R; ++q)
-            if (all[3 * static_cast<size_t>(q) + 2])
-                throw std::runtime_error(q == r ? "sharded step failed on this rank: " + local_error
-                                                : "sharded step failed on rank " + std::to_string(q));
-        std::vector<uint64_t> P(R + 1);
-        P[0] = sh_pairs_;
-        for (int q = 0; q < R; ++q)
-            P[q + 1] = P[q] + all[3 * static_cast<size_t>(q)];
-        auto first_frame = [&](uint64_t pair) { return (2 * pair + nct - 1) / nct; }; // first frame whose first pair is >= pair
-        if (first_frame(P[0]) != frame_pos_)
-            throw std::runtime_error("sharded stream out of step");
-        for (int q = 0; q < R; ++q) // the same checks on every rank, for every rank
-        {
-            const uint64_t f0 = first_frame(P[q]), nq = first_frame(P[q + 1]) - f0;
-            if (nq > cap)
-                throw std::runtime_error("sharded step: more frames in a piece than the output buffers hold");
-            if (nq && ((f0 + nq) * nct - 1) / 2 - P[q] + 1 > all[3 * static_cast<size_t>(q) + 1])
-                throw std::runtime_error("sharded step: a frame extends beyond the margin generated after the piece");
-        }
-        st.first = first_frame(P[r]);
-        st.n = first_frame(P[r + 1]) - st.first;
-        st.step_frames = first_frame(P[R]) - st.step_first;
+        const ShardPlacement pl = place_pieces(all.data(), R, r, sh_pairs_, frame_pos_, nct, cap, local_error); // (shard_place.hpp)
+        st.first = pl.first, st.n = pl.n, st.step_frames = pl.step_frames;
         hipStream_t s = static_cast<hipStream_t>(rng_stream_), user = static_cast<hipStream_t>(stream);
         check(hipEventRecord(static_cast<hipEvent_t>(ev_pairs_ready_[buf]), s), "event");
         check(hipStreamWaitEvent(user, static_cast<hipEvent_t>(ev_pairs_ready_[buf]), 0), "wait pairs ready");
         a.mode = kModeAwgn;
-        fill_slab_args(a, np, P[r], buf);
+        fill_slab_args(a, np, pl.pair_start, buf);
         a.normal_base = st.first * nct;
-        sh_pairs_ = P[R];
+        sh_pairs_ = pl.pairs_after;
         sh_chunk_ += stride;
     }
     else
     {
+        if (failed_before) // (no exchange inside a BSC / BEC step: the caller's own exchange carries the failure)
+            throw std::runtime_error(*failed_before);
         if (cap > max_sub_batch())
             throw std::runtime_error("sharded step too large for one launch per rank");
         st.step_frames = target_frames;

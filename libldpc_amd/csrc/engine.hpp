@@ -199,7 +199,8 @@ class Engine
         uint64_t step_first = 0, step_frames = 0; // the global step
         uint64_t first = 0, n = 0;                // this rank's frames [first, first + n)
     };
-    ShardStep stream_decode_sharded(Comm &comm, const DecParams &p, uint64_t target_frames, const BatchOut &out, void *stream);
+    ShardStep stream_decode_sharded(Comm &comm, const DecParams &p, uint64_t target_frames, const BatchOut &out, void *stream,
+                                    const std::string *failed_before = nullptr);
     // encoder state (info-word stream position + accumulated codeword) saved before a step / put back and advanced by
     // `frames` frames: how every rank lands on the state after the frame at which the simulation stopped
     void encoder_snapshot(void *stream);

@@ -83,7 +83,15 @@ int run_simulation_sharded(Engine &eng, const SimRequest &rq, sim_results_t *res
         const auto t_start = clock::now();
         eng.stream_begin(rq.channel, rq.seed, xs[i], /*fresh=*/i == 0);
         const uint64_t msb = eng.max_sub_batch() * 3 / 4; // (a piece may hold a few per cent more frames than its share)
-        const uint64_t max_step = std::max<uint64_t>(1, std::min<uint64_t>(rq.max_batch, msb)) * R;
+        uint64_t max_step = std::max<uint64_t>(1, std::min<uint64_t>(rq.max_batch, msb)) * R;
+        // a piece is at least one whole generator chunk: for very short codes that is more frames than one launch takes, however
+        // small the step (round-3 ADVICE) — such a code is turned away here, with a reason, on every rank alike; otherwise the
+        // largest step is brought down to what the output buffers of one launch per rank hold
+        while (max_step > static_cast<uint64_t>(R) && eng.shard_capacity(max_step, R) > eng.max_sub_batch())
+            max_step = std::max<uint64_t>(R, max_step * 3 / 4);
+        if (eng.shard_capacity(max_step, R) > eng.max_sub_batch())
+            throw std::runtime_error("sharded simulation: one generator chunk of the noise stream holds more frames of this code than one "
+                                     "launch takes (very short code): run it on one rank, or with a smaller LDPC_AMD_CHUNK_BLOCKS");
         const uint64_t min_step = std::min<uint64_t>(rq.first_batch, max_step);
         uint64_t step = min_step;
         bool go = true;
@@ -98,10 +106,21 @@ int run_simulation_sharded(Engine &eng, const SimRequest &rq, sim_results_t *res
             Engine::ShardStep st;
             std::string step_error;
             Fold mine;
+            // (the encoder snapshot comes before the step's own exchange: if it fails here, the step is entered with the failure
+            // in hand so that this rank still takes part in that exchange — round-3 ADVICE: it used to go straight to the
+            // exchange below while the other ranks sat in the step's)
+            std::string snap_error;
             try
             {
                 eng.encoder_snapshot(nullptr);
-                st = eng.stream_decode_sharded(comm, rq.dec, step, out, nullptr);
+            }
+            catch (const std::exception &e)
+            {
+                snap_error = e.what();
+            }
+            try
+            {
+                st = eng.stream_decode_sharded(comm, rq.dec, step, out, nullptr, snap_error.empty() ? nullptr : &snap_error);
                 // every rank's range as if all of it counted; the ranks before the one holding the stopping frame do
                 mine = fold_range(it_buf.data(), be_buf.data(), st.n, 0, 0, kNoLimit, kNoLimit);
             }
@@ -194,7 +213,12 @@ int run_simulation_sharded(Engine &eng, const SimRequest &rq, sim_results_t *res
                     want = static_cast<uint64_t>(per_err * static_cast<double>(rq.min_fec - fec) * 1.25) + 1;
                 }
                 want = std::min<uint64_t>(want, rq.max_frames - frames);
-                step = std::clamp<uint64_t>(want, min_step, max_step);
+                // a few step sizes only (powers of two between the smallest and the largest): every new size is a new piece
+                // geometry — jump polynomials multiplied on the host, a table re-seek — inside the step (round-3 ADVICE)
+                uint64_t q = min_step;
+                while (q < want && q < max_step)
+                    q = std::min<uint64_t>(q * 2, max_step);
+                step = std::clamp<uint64_t>(q, min_step, max_step);
             }
         }
         if (rq.cli_output && root)

@@ -300,7 +300,7 @@ from libldpc_amd import shard
 dist.init_process_group("gloo")                      # two ranks share the one GPU of the test box
 rank, _, world = shard.rank_world()
 per_rank = 700
-lo, hi = shard.frame_range(rank, world, per_rank)
+lo, hi = rank * per_rank, (rank + 1) * per_rank   # a caller's own contiguous split: stream_skip + stream_decode
 d = libldpc_amd.HipDecoder(%r, device=0)
 d.stream_begin("AWGN", 0, -4.0)
 if lo:
@@ -308,16 +308,17 @@ if lo:
 r = d.stream_decode(hi - lo, want=("iters", "bit_errors"))
 c = shard.counters_from_outputs(torch, torch.from_numpy(r["iters"].astype(np.int32)),
                                 torch.from_numpy(r["bit_errors"].astype(np.int32)), 50, True)
-c = shard.reduce_counters(c, dist)
+dist.all_reduce(c)
 np.save(os.path.join(%r, "counters%%d.npy" %% rank), c.numpy())
 dist.destroy_process_group()
 '''
 
 
 def test_two_ranks_count_what_one_rank_counts(dec, tmp_path):
-    """SURVEY §8e: frames keep their identity in the one RNG stream, so the counters two ranks reduce over their
-    contiguous frame ranges equal the counters of a single rank decoding all frames (here both ranks use cuda:0
-    and the reduce runs over gloo; on a node it is one rank per GPU over RCCL)."""
+    """SURVEY §8e: frames keep their identity in the one RNG stream, so the counters two ranks reduce over contiguous
+    frame ranges of their own choosing (stream_skip + stream_decode: the caller-side way to split a stream; the library's
+    own sharded step, which splits the RAW stream, is tests/test_shard.py) equal the counters of a single rank decoding
+    all frames (both ranks use cuda:0, the reduce runs over gloo)."""
     import sys
     import torch
     from libldpc_amd import shard
@@ -388,7 +389,7 @@ def test_8k_bulk_bit_exact_vs_det_oracle(dec8k, h8k_file, x, ms, early, iters, n
     import multiprocessing as mp
     parts = 16
     per = n // parts
-    with mp.get_context("fork").Pool(parts) as pool:
+    with mp.get_context("spawn").Pool(parts) as pool:
         res = pool.map(_oracle_chunk_file, [(h8k_file, "AWGN", x, 6, k * per, per, ms, early, iters) for k in range(parts)])
     it = np.concatenate([r[0] for r in res])
     be = np.concatenate([r[1] for r in res])

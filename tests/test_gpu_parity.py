@@ -216,7 +216,7 @@ def test_bulk_131072_frames_bit_exact_vs_det_oracle(dec):
     import multiprocessing as mp
     n, parts = 131072, 16
     per = n // parts
-    with mp.get_context("fork").Pool(parts) as pool:
+    with mp.get_context("spawn").Pool(parts) as pool:
         res = pool.map(_oracle_chunk, [(-4.0, 0, k * per, per) for k in range(parts)])
     it = np.concatenate([r[0] for r in res])
     be = np.concatenate([r[1] for r in res])
@@ -250,7 +250,7 @@ def test_bulk_other_modes_bit_exact_vs_det_oracle(dec, chan, x, ms, n):
     import multiprocessing as mp
     parts = 16
     per = n // parts
-    with mp.get_context("fork").Pool(parts) as pool:
+    with mp.get_context("spawn").Pool(parts) as pool:
         res = pool.map(_oracle_chunk, [(x, 4, k * per, per, chan, ms) for k in range(parts)])
     it = np.concatenate([r[0] for r in res])
     be = np.concatenate([r[1] for r in res])

@@ -87,7 +87,7 @@ def test_config3_bulk_bit_exact_vs_reference_arithmetic(dec):
     the whole fused path equals the det-mode oracle frame by frame."""
     n, parts = 8192, 16
     per = n // parts
-    with mp.get_context("fork").Pool(parts) as pool:
+    with mp.get_context("spawn").Pool(parts) as pool:
         res = pool.map(_libm_chunk, [("AWGN", -4.0, 0, k * per, per, True, False, 50, True) for k in range(parts)])
         det = pool.map(_det_chunk, [("AWGN", -4.0, 0, k * per, per, True, False, 50) for k in range(parts)])
     ref = {key: np.concatenate([o[key] for o in res]) for key in ("iters", "bit_errors", "hard", "llr_out", "llr_in")}
@@ -110,7 +110,7 @@ def test_bec_bulk_16384_frames_vs_reference_arithmetic():
     d.set_bec_compat(True)
     n, parts = 16384, 16
     per = n // parts
-    with mp.get_context("fork").Pool(parts) as pool:
+    with mp.get_context("spawn").Pool(parts) as pool:
         res = pool.map(_bec_chunk, [(k * per, per) for k in range(parts)])
     d.stream_begin("BEC", 3, 0.9)
     r = d.stream_decode(n, want=("iters", "bit_errors", "hard"))

@@ -151,31 +151,71 @@ def test_missing_library_is_an_error(tmp_path):
         libldpc_amd.load_library(str(tmp_path / "libldpc.so"))
 
 
-WORKER = r'''
-import os, sys, torch, torch.distributed as dist
+WORKER = r"""
+import os, sys, numpy as np, torch.distributed as dist
 sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import libldpc_amd, orc
 from libldpc_amd import shard
 dist.init_process_group("gloo")
 rank, _, world = shard.rank_world()
-per_rank = 1000
-lo, hi = shard.frame_range(rank, world, per_rank)
-g = torch.Generator().manual_seed(1234)                 # every rank sees the same "global" per-frame results
-iters = torch.randint(1, 51, (world * per_rank,), generator=g, dtype=torch.int32)
-be = (torch.rand(world * per_rank, generator=g) < 0.01).to(torch.int32) * 7
-c = shard.counters_from_outputs(torch, iters[lo:hi], be[lo:hi], 50, True)
-c = shard.reduce_counters(c, dist)
-ref = shard.counters_from_outputs(torch, iters, be, 50, True)  # what one rank alone would count
-assert torch.equal(c, ref), (c, ref)
-assert (lo, hi) == (rank * per_rank, (rank + 1) * per_rank)
+# the real exchange of the sharded step runs over the library's own communicator (host shared memory here, RCCL on a
+# node); gloo only hands out the segment's name and collects the ranks' answers for the comparison
+box = ["/ldpc_place_%%d" %% os.getpid() if rank == 0 else None]
+dist.broadcast_object_list(box, src=0)
+comm = libldpc_amd.Comm(rank, world, shm_name=box[0])
+# a recorded stretch of the reference's noise stream: which polar trials libstdc++'s normal_distribution accepts
+nct, chunk_trials, m, margin, steps = 1024, 4096, 2, 1400, 3
+n_trials = steps * world * m * chunk_trials + margin
+w = orc.mt64_stream(0, 2 * n_trials).astype(np.float64) * 2.0 ** -64
+x, y = 2.0 * w[0::2] - 1.0, 2.0 * w[1::2] - 1.0
+r2 = x * x + y * y
+acc = (r2 <= 1.0) & (r2 != 0.0)
+cum = np.concatenate([[0], np.cumsum(acc)])                       # accepted pairs before trial t
+pairs_before, frame_pos, mine = 0, 0, []
+for s in range(steps):
+    lo = (s * world + rank) * m * chunk_trials
+    piece = int(cum[lo + m * chunk_trials] - cum[lo])
+    with_margin = int(cum[lo + m * chunk_trials + margin] - cum[lo])
+    first, n, step_frames, pair_start, pairs_after = comm.place(nct, pairs_before, frame_pos, 64, piece, with_margin)
+    assert pair_start == int(cum[lo]), (pair_start, int(cum[lo]))  # the piece starts where the stream says it does
+    mine.append((first, n, step_frames, pairs_after))
+    pairs_before, frame_pos = pairs_after, frame_pos + step_frames
+every = [None] * world
+dist.all_gather_object(every, mine)
+for s in range(steps):
+    assert len({(e[s][2], e[s][3]) for e in every}) == 1         # every rank computed the same step
+    f = every[0][s][0]
+    for q in range(world):                                        # the pieces' frames are contiguous, in rank order
+        assert every[q][s][0] == f, (s, q)
+        f += every[q][s][1]
+    lo_step = s * world * m * chunk_trials
+    for q in range(world):                                        # a frame belongs to the piece that holds its first pair
+        p_lo, p_hi = int(cum[lo_step + q * m * chunk_trials]), int(cum[lo_step + (q + 1) * m * chunk_trials])
+        for fr in range(every[q][s][0], every[q][s][0] + every[q][s][1]):
+            assert p_lo <= fr * nct // 2 < p_hi, (s, q, fr)
+    assert every[world - 1][s][0] + every[world - 1][s][1] == -(-2 * every[0][s][3] // nct)  # nothing left out
+# a failure reported by one rank reaches every rank in the same call
+try:
+    comm.place(nct, pairs_before, frame_pos, 64, 1000, 2000, status=1 if rank == 1 else 0)
+    raise SystemExit("a failed rank went unnoticed")
+except RuntimeError as e:
+    assert ("on this rank" if rank == 1 else "on rank 1") in str(e), str(e)
+st = comm.exchange_stats()
+assert st["calls"] == steps + 1 and st["min"] > 0 and comm.describe() == "shm"
+comm.close()
 dist.destroy_process_group()
 open(os.path.join(%r, "ok%%d" %% rank), "w").write("ok")
-'''
+"""
 
 
-def test_sharded_counters_equal_single_shard_gloo(tmp_path):
-    """world_size 2 over gloo: the summed per-shard counters equal the single-shard counters (SURVEY §8e)."""
+def test_sharded_step_placement_two_ranks_gloo(tmp_path):
+    """world_size 2 on the CPU: the placement step of the sharded AWGN step (libldpc_amd/csrc/shard_place.hpp: the all-gather
+    of the accepted-pair counts and what every rank derives from it) over the library's shared-memory communicator, on a
+    recorded stretch of the reference's noise stream — every frame goes to the rank whose piece holds its first pair, the
+    pieces' frames are contiguous and complete, all ranks agree on the step, a failed rank fails every rank."""
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % (ROOT, str(tmp_path)))
+    script.write_text(WORKER % (ROOT, ROOT, str(tmp_path)))
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
                        capture_output=True, text=True, timeout=300)
@@ -184,64 +224,23 @@ def test_sharded_counters_equal_single_shard_gloo(tmp_path):
 
 
 def test_headline_kernel_register_budget():
-    """The likelihood-ratio decode kernel of the n=1024 code runs five frames per CU only while it fits 96 VGPRs
-    (512 / 5 waves per SIMD, allocated in eights) without scratch; the compiler's resource report of the last build
-    (libldpc_amd/build.py keeps it next to the object) must still say so.  Several attempted optimisations were
-    lost to exactly this boundary (profiles/README.md)."""
+    """The headline kernel (fused form of the first ratio launch, kernels_fused.hip: decode_fused_small) runs SIX frames per CU
+    only while it fits 80 VGPRs (512 / 6 waves per SIMD, allocated in eights) without scratch; the general LDS-resident
+    ratio / min-sum kernel of the n=1024 code (decode_kernel_w5, still the min-sum kernel and the second launch's
+    neighbour) five while it fits 96.  The compiler's resource report of the last build (libldpc_amd/build.py keeps it
+    next to the object) must still say so: the wrappers pin the waves per SIMD, so a regression shows up as scratch
+    (spills), not as a lower occupancy.  Several attempted optimisations were lost to exactly these boundaries
+    (profiles/README.md)."""
     from libldpc_amd import build
-    res = build.kernel_resources("kernels.hip")
-    if res is None:
+    res, fused = build.kernel_resources("kernels.hip"), build.kernel_resources("kernels_fused.hip")
+    if res is None or fused is None:
         pytest.skip("no resource report (library built by something other than libldpc_amd.build)")
-    # decode_kernel_w5<MINSUM=false, WANT_LLR=false, LDS_RESIDENT=true, MAXD=4, LLR_MODE=kLlrRegs, RATIO=true>: the
-    # wrapper pins five waves per SIMD, so a regression shows up as scratch (spills), not as a lower occupancy
+    key = [k for k in fused if "decode_fused_small" in k]
+    assert len(key) == 1, key
+    r = fused[key[0]]
+    assert r["VGPRs"] <= 80 and r["ScratchSize [bytes/lane]"] == 0 and r["Occupancy [waves/SIMD]"] >= 6, r
+    # decode_kernel_w5<MINSUM=false, WANT_LLR=false, LDS_RESIDENT=true, MAXD=4, LLR_MODE=kLlrRegs, RATIO=true>
     key = [k for k in res if "decode_kernel_w5ILb0ELb0ELb1ELi4ELi2ELb1E" in k]
     assert len(key) == 1, key
     r = res[key[0]]
     assert r["VGPRs"] <= 96 and r["ScratchSize [bytes/lane]"] == 0 and r["Occupancy [waves/SIMD]"] >= 5, r
-    # the min-sum instantiation of the same code (BASELINE config 3)
-    key = [k for k in res if "decode_kernel_w5ILb1ELb0ELb1ELi4ELi2ELb0E" in k]
-    assert len(key) == 1 and res[key[0]]["VGPRs"] <= 96 and res[key[0]]["ScratchSize [bytes/lane]"] == 0, res[key[0]]
-
-
-def test_reference_pyldpc_wrapper_outputs():
-    """tests/golden/pyldpc_host.json was recorded by the REFERENCE's pyLDPC/ldpc.py (unmodified, imported from the
-    reference checkout in the build container) driving libldpc_amd/libldpc.so through ctypes, and is equal there to the
-    same calls against the reference's own library (make_pyldpc.py asserts it).  Here: our same-shaped wrapper over the
-    library as built now returns exactly those values — setup dimensions, rank, encode, syndrome (no GPU needed)."""
-    import json
-    import libldpc_amd
-    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "pyldpc_host.json")))
-    c = libldpc_amd.LDPC(orc.H_TXT, orc.G_TXT)
-    assert [c.n, c.m, c.nct, c.mct, c.k, c.kct] == fx["dims"]
-    assert c.rank() == fx["rank"]
-    for e in fx["encode"]:
-        assert [int(v) for v in c.encode(np.array(e["info"]))] == e["codeword"]
-    for e in fx["syndrome"]:
-        assert [int(v) for v in c.syndrome(np.array(e["word"]))] == e["syndrome"]
-
-
-def test_totals_form_plan_layout(h8k_file, tmp_path):
-    """The LDS layout and packed edge words of the second register-resident kernel (plan.cpp build_reg2_plan), checked on
-    the host by tools/reg2_plan_stats.cpp: every edge lands in its own round's mailbox entry and in the trash entry in
-    the other round (the kernel's address arithmetic replayed), no entry has two writers, totals are distinct, 160 KB
-    hold; the (3,6) n=8192 code takes the regular-code instantiation, an irregular code the generic one; the bank-aware
-    placement keeps its conflict levels."""
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from test_gpu_random_codes import make_code_by_degrees
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "reg2_plan_stats")
-    subprocess.check_call(["g++", "-O2", "-std=c++20", "-I" + os.path.join(root, "libldpc_amd", "csrc"),
-                           os.path.join(root, "tools", "reg2_plan_stats.cpp"), os.path.join(root, "libldpc_amd", "csrc", "plan.cpp"),
-                           os.path.join(root, "libldpc_amd", "csrc", "code.cpp"), "-o", exe])
-    irr = make_code_by_degrees(str(tmp_path / "irr.txt"), [2] * 3008 + [3] * 4928, [5] * 560 + [6] * 3000, np.random.default_rng(11))
-    for path, regular in ((h8k_file, "yes"), (irr, "no")):
-        p = subprocess.run([exe, path], stdout=subprocess.PIPE, text=True)
-        assert p.returncode == 0, p.stdout
-        assert f"invariant violations: 0   regular-code instantiation: {regular}" in p.stdout
-        gather = float(re.search(r"gather: ([0-9.]+)", p.stdout).group(1))
-        scatter = [float(x) for x in re.search(r"round 0 ([0-9.]+), round 1 ([0-9.]+)", p.stdout).groups()]
-        assert gather <= 4.1 and max(scatter) <= 6.5, p.stdout  # natural order: 7.0 and 8.8
-    # a code with a degree-1 variable node is left to the messages form
-    leaf = make_code_by_degrees(str(tmp_path / "leaf.txt"), [1] * 64 + [2] * 2976 + [3] * 4928, [5] * 560 + [6] * 3000, np.random.default_rng(12))
-    p = subprocess.run([exe, leaf], stdout=subprocess.PIPE, text=True)
-    assert p.returncode == 1 and "plan refused" in p.stdout

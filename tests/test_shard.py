@@ -156,6 +156,53 @@ def _failing_worker(rank, world, name, q):
         q.put((rank, str(e)))
 
 
+def _failing_sim_worker(rank, world, name, q):
+    sys.path.insert(0, ROOT)
+    os.environ["LDPC_AMD_COMM_TIMEOUT_S"] = "60"
+    import time
+    import libldpc_amd
+    dec = libldpc_amd.HipDecoder(orc.H_TXT, orc.G_TXT, device=0 if rank == 0 else 7)  # with G: the loop snapshots the encoder
+    comm = libldpc_amd.Comm(rank, world, shm_name=name)
+    t0 = time.time()
+    try:
+        dec.simulate("AWGN", [-4.0, -3.9, 1.0], max_frames=2000, fec=5, comm=comm)
+        q.put((rank, "no error", time.time() - t0))
+    except Exception as e:
+        q.put((rank, str(e), time.time() - t0))
+
+
+def _failing_sim(world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"/ldpc_amd_test_{os.getpid()}_fsim"
+    ps = [ctx.Process(target=_failing_sim_worker, args=(r, world, name, q)) for r in range(world)]
+    [p.start() for p in ps]
+    got = {}
+    for _ in range(world):
+        rank, msg, dt = q.get(timeout=180)
+        got[rank] = (msg, dt)
+    [p.join(timeout=60) for p in ps]
+    return got
+
+
+def test_sharded_simulation_failure_with_generator_reaches_every_rank():
+    """Round-3 ADVICE: with a generator matrix loaded the simulation loop snapshots the encoder before the sharded step; a rank
+    on which that fails (no usable device) must still take part in the step's own exchange, or the other ranks sit in it
+    while this one has moved on to the loop's.  Every rank returns an error from ldpc_hip_simulate_sharded, promptly.  (No
+    GPU here: both ranks fail; test_..._one_rank_only below is the asymmetric case on the GPU box.)"""
+    got = _failing_sim()
+    for r in range(2):
+        assert got[r][0] != "no error" and got[r][1] < 30, got
+
+
+@pytest.mark.gpu
+def test_sharded_simulation_failure_with_generator_one_rank_only():
+    """The same with rank 0 on the GPU and rank 1 on a device that does not exist: rank 0 learns of the failure in the step's
+    exchange and both return an error within seconds."""
+    got = _failing_sim()
+    assert "rank 1" in got[0][0] and got[0][1] < 30 and got[1][0] != "no error" and got[1][1] < 30, got
+
+
 def _cli(args, out, extra=()):
     exe = os.path.join(ROOT, "libldpc_amd", "ldpcsim")
     subprocess.check_call([exe, orc.H_TXT, str(out)] + list(args) + list(extra), stdout=subprocess.DEVNULL)
@@ -196,3 +243,105 @@ def test_rccl_communicator_single_rank_and_sharded_step():
     ref = dec.stream_decode(n)
     assert np.array_equal(np.concatenate(got_it), ref["iters"]) and np.array_equal(np.concatenate(got_be), ref["bit_errors"])
     comm.close()
+
+
+def _rccl_worker(rank, world, id_q, case, q, code_file):
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("LDPC_AMD_COMM_TIMEOUT_S", "120")
+    import libldpc_amd
+    chan, x, seed, target, steps, decoding = case
+    try:
+        if rank == 0:
+            uid = libldpc_amd.Comm.unique_id()
+            for _ in range(world - 1):
+                id_q.put(uid)
+        else:
+            uid = id_q.get(timeout=120)
+        dec = libldpc_amd.HipDecoder(code_file, device=rank)
+        comm = libldpc_amd.Comm(rank, world, device=rank, unique_id=uid)  # ncclCommInitRank: one rank per GPU
+        dec.stream_begin(chan, seed, x)
+        out = []
+        for _ in range(steps):
+            bufs, step = dec.stream_decode_sharded(comm, target, decoding=decoding)
+            out.append((step, bufs["iters"][:step[3]].copy(), bufs["bit_errors"][:step[3]].copy()))
+        q.put((rank, out, comm.describe(), comm.exchange_stats()))
+        comm.close()
+    except Exception as e:  # (the parent must not wait for a rank that failed)
+        q.put((rank, repr(e), "", {}))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("code", ["h", "8k"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_frames_keep_their_results_rccl(world, code, h8k_file):
+    """The real thing, the day a node with several GPUs runs the suite: one process per GPU, the sharded step over RCCL
+    (ncclCommInitRank with world > 1, ncclAllGather between processes over xGMI), on the n = 1024 code and on the code
+    BASELINE.json shards — every frame has the iteration count and bit-error count of the one-rank run, whichever GPU decoded
+    it.  Skipped where fewer than `world` GPUs are visible (the one-GPU rehearsals above cover the same code over shm)."""
+    import torch
+    if torch.cuda.device_count() < world:  # (counting devices does not initialise the GPU)
+        pytest.skip(f"needs {world} GPUs, {torch.cuda.device_count()} visible")
+    import libldpc_amd
+    code_file = orc.H_TXT if code == "h" else h8k_file
+    case = ("AWGN", -4.0, 0, 3000 * world, 3, "BP") if code == "h" else ("AWGN", 2.0, 0, 300 * world, 3, "BP")
+    ctx = mp.get_context("spawn")  # fresh processes: none inherits an initialised HIP runtime
+    q, id_q = ctx.Queue(), ctx.Queue()
+    ps = [ctx.Process(target=_rccl_worker, args=(r, world, id_q, case, q, code_file)) for r in range(world)]
+    [p.start() for p in ps]
+    got = {}
+    for _ in range(world):
+        rank, out, desc, stats = q.get(timeout=600)
+        assert not isinstance(out, str), f"rank {rank}: {out}"
+        got[rank] = out
+        assert desc.startswith("rccl") and stats["calls"] == case[4]
+    [p.join(timeout=120) for p in ps]
+    total = got[0][-1][0][0] + got[0][-1][0][1]
+    dec = libldpc_amd.HipDecoder(code_file)
+    dec.stream_begin(case[0], case[2], case[1])
+    ref = dec.stream_decode(total, decoding=case[5])
+    pos = 0
+    for s in range(case[4]):
+        step0 = got[0][s][0]
+        assert step0[0] == pos
+        nxt = step0[0]
+        for r in range(world):
+            step, it, be = got[r][s]
+            assert step[:2] == step0[:2] and step[2] == nxt
+            assert np.array_equal(it, ref["iters"][step[2]:step[2] + step[3]]), (s, r)
+            assert np.array_equal(be, ref["bit_errors"][step[2]:step[2] + step[3]]), (s, r)
+            nxt += step[3]
+        assert nxt == step0[0] + step0[1]
+        pos = nxt
+
+
+def _timeout_worker(rank, name, q):
+    sys.path.insert(0, ROOT)
+    os.environ["LDPC_AMD_COMM_TIMEOUT_S"] = "2"
+    import time
+    import libldpc_amd
+    comm = libldpc_amd.Comm(rank, 2, shm_name=name)
+    comm.all_gather(np.array([rank], np.uint64))
+    if rank == 1:
+        q.put((rank, "left"))  # this rank leaves the job: it never joins the second exchange
+        return
+    t0 = time.time()
+    try:
+        comm.all_gather(np.array([rank], np.uint64))
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, f"{time.time() - t0:.1f}s {e}"))
+
+
+def test_exchange_gives_up_on_a_rank_that_left():
+    """No wait in the exchange is unbounded: a rank whose peer has left the job gets an error after the deadline
+    (LDPC_AMD_COMM_TIMEOUT_S; RCCL: the same deadline around ncclCommInitRank and the all-gather's stream) instead of
+    spinning for ever.  CPU, shared-memory transport."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"/ldpc_amd_test_{os.getpid()}_to"
+    ps = [ctx.Process(target=_timeout_worker, args=(r, name, q)) for r in range(2)]
+    [p.start() for p in ps]
+    got = dict(q.get(timeout=120) for _ in range(2))
+    [p.join(timeout=60) for p in ps]
+    assert got[1] == "left" and "did not arrive" in got[0] and float(got[0].split("s ")[0]) < 30, got

@@ -778,6 +778,9 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         // the first launch of sum-product with early termination, for codes the fused form takes (fused_rule.h)
         if (fused_plan_.ok && !p.min_sum && p.early_term && a.redo_list && !a.redo_count_in && !a.ratio_separate)
             check(launch_decode_fused(a, dev_fused_, s), "decode (fused form)");
+        else if (fused_plan_.ok && p.min_sum && !p.early_term && p.iterations > 0 && !a.redo_list && !a.redo_count_in &&
+                 !std::getenv("LDPC_AMD_NO_FUSED_MS"))
+            check(launch_decode_fused_minsum(a, dev_fused_, s), "decode (min-sum, fused plan)");
         else if (plan_.lds_ok)
         {
             // Input LLRs: in registers when that frees the LDS for one more resident frame per CU (n=1024 code:

@@ -143,6 +143,8 @@ struct DevFusedPlan
 };
 // first launch of sum-product with early termination (a.redo_list / a.redo_count set, a.early_term, no a.redo_count_in)
 int launch_decode_fused(const DecodeArgs &a, const DevFusedPlan &f, void *stream);
+// min-sum without early termination on the same plan (no redo lists)
+int launch_decode_fused_minsum(const DecodeArgs &a, const DevFusedPlan &f, void *stream);
 
 // BEC (u8 erasure alphabet, decoder.cpp:91-192 + channel.cpp:199-229)
 struct BecArgs

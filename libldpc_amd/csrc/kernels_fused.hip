@@ -25,6 +25,7 @@
 
 #include <algorithm>
 
+#include "device_cn.hpp"
 #include "device_math.hpp"
 #include "fused_rule.h"
 #include "kernels.hpp"
@@ -295,6 +296,83 @@ __device__ __forceinline__ AwgnFrame awgn_frame(const DecodeArgs &a, uint64_t fr
     return f;
 }
 
+// ---- prologue, part 1 of both forms: the frame's input LLRs, one per transmitted bit (AWGN / BSC: entry i = transmitted bit i,
+// entry nct = the value of a shortened bit) or per column (given LLRs), spread evenly over the workgroup's threads;
+// put(entry, L) stages what the form keeps of it.  Returns false when the frame's normals cannot be addressed here
+// (awgn_frame).  channel.cpp:62-93 / 129-162, shared.cpp:50-55.
+template <typename Put>
+__device__ __forceinline__ bool stage_channel(const DecodeArgs &a, const DevFusedPlan &F, uint64_t frame, int tid, Put &&put)
+{
+    const DevPlan &P = a.plan;
+    const int nc = P.nc, nct = P.nct;
+    const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
+    const bool given = a.mode == kModeLlr;
+    const int n_stage = given ? nc : nct;
+    bool ok = true;
+    double *dump = a.llr_in_dump ? a.llr_in_dump + frame * nc : nullptr;
+    if (dump && !given) // columns the channel does not write: punctured 0.0, shortened (channel.cpp:73-86)
+        for (int r = tid; r < nc; r += kThreads)
+            if (const uint8_t k = P.rank_kind[r]; k != 0)
+                dump[P.rank_col[r]] = k == 2 ? a.shorten_llr : 0.0;
+    if (given)
+    {
+        const double *in = a.llr_in + frame * nc;
+        for (int s = tid; s < n_stage; s += kThreads)
+        {
+            const double L = in[s];
+            if (dump)
+                dump[s] = L;
+            put(s, L);
+        }
+    }
+    else if (a.mode == kModeAwgn)
+    {
+        const AwgnFrame f = awgn_frame(a, frame, nct);
+        ok = f.ok;
+        if (f.ok)
+            for (int i = tid; i < n_stage; i += kThreads)
+            {
+                const uint32_t ui = static_cast<uint32_t>(i);
+                const uint32_t off = ui + (ui >= f.t1 ? f.d1 : 0u) + (ui >= f.t2 ? f.d2 : 0u);
+                const uint64_t w = __builtin_nontemporal_load(f.p0 + off);
+                int xb = 0;
+                int col = 0;
+                if (cw || dump)
+                    col = P.bit_pos[i];
+                if (cw)
+                    xb = static_cast<int>(cw[col]);
+                const double noise = dm_from_bits(w) * a.sigma + 0.0; // channel.cpp:62-68
+                const double xs = cw ? static_cast<double>(1 - 2 * xb) : 1.0;
+                const double y = noise + xs;
+                const double L = 2 * y / a.sigma2; // channel.cpp:88-92
+                if (dump)
+                    dump[col] = L;
+                put(i, L);
+            }
+    }
+    else // kModeBsc (channel.cpp:129-162)
+    {
+        const uint64_t *raw = a.raw + frame * static_cast<uint64_t>(nct);
+        for (int i = tid; i < n_stage; i += kThreads)
+        {
+            int xb = 0, col = 0;
+            if (cw || dump)
+                col = P.bit_pos[i];
+            if (cw)
+                xb = static_cast<int>(cw[col]);
+            const int flip = canonical(raw[i]) < a.eps;
+            const int y = xb ^ flip;
+            const double L = a.delta * static_cast<double>(1 - 2 * y);
+            if (dump)
+                dump[col] = L;
+            put(i, L);
+        }
+    }
+    if (tid == kThreads - 1 && F.has_shortened && !given)
+        put(n_stage, a.shorten_llr);
+    return ok;
+}
+
 // =======================================================================================================================
 template <bool WANT_LLR, int VNB, int CNL, bool EXCL>
 __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPlan &F)
@@ -326,72 +404,10 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
             const double lam = dm_exp_clamped(0.0 - L);
             stage[s] = double2{lam, dm_ratio_div(1.0, lam)};
         };
-        double *dump = a.llr_in_dump ? a.llr_in_dump + frame * nc : nullptr;
-        if (dump && !given) // columns the channel does not write: punctured 0.0, shortened (channel.cpp:73-86)
-            for (int r = tid; r < nc; r += kThreads)
-                if (const uint8_t k = P.rank_kind[r]; k != 0)
-                    dump[P.rank_col[r]] = k == 2 ? a.shorten_llr : 0.0;
-        if (given)
-        {
-            const double *in = a.llr_in + frame * nc;
-            for (int s = tid; s < n_stage; s += kThreads)
-            {
-                const double L = in[s];
-                if (dump)
-                    dump[s] = L;
-                put(s, L);
-            }
-        }
-        else if (a.mode == kModeAwgn)
-        {
-            const AwgnFrame f = awgn_frame(a, frame, nct);
-            if (!f.ok)
-                t.hmax = 0xFFFFFFFFu;
-            else
-                for (int i = tid; i < n_stage; i += kThreads)
-                {
-                    const uint32_t ui = static_cast<uint32_t>(i);
-                    const uint32_t off = ui + (ui >= f.t1 ? f.d1 : 0u) + (ui >= f.t2 ? f.d2 : 0u);
-                    const uint64_t w = __builtin_nontemporal_load(f.p0 + off);
-                    int xb = 0;
-                    int col = 0;
-                    if (cw || dump)
-                        col = P.bit_pos[i];
-                    if (cw)
-                        xb = static_cast<int>(cw[col]);
-                    const double noise = dm_from_bits(w) * a.sigma + 0.0; // channel.cpp:62-68
-                    const double xs = cw ? static_cast<double>(1 - 2 * xb) : 1.0;
-                    const double y = noise + xs;
-                    const double L = 2 * y / a.sigma2; // channel.cpp:88-92
-                    if (dump)
-                        dump[col] = L;
-                    put(i, L);
-                }
-        }
-        else // kModeBsc (channel.cpp:129-162)
-        {
-            const uint64_t *raw = a.raw + frame * static_cast<uint64_t>(nct);
-            for (int i = tid; i < n_stage; i += kThreads)
-            {
-                int xb = 0, col = 0;
-                if (cw || dump)
-                    col = P.bit_pos[i];
-                if (cw)
-                    xb = static_cast<int>(cw[col]);
-                const int flip = canonical(raw[i]) < a.eps;
-                const int y = xb ^ flip;
-                const double L = a.delta * static_cast<double>(1 - 2 * y);
-                if (dump)
-                    dump[col] = L;
-                put(i, L);
-            }
-        }
+        if (!stage_channel(a, F, frame, tid, put))
+            t.hmax = 0xFFFFFFFFu;
         if (tid == kThreads - 1)
-        {
-            if (F.has_shortened && !given)
-                put(n_stage, a.shorten_llr);
             stage[n_stage + 1] = double2{1.0, 1.0}; // L = 0: punctured, never written by the channel, no node
-        }
     }
 
     // what the lane keeps for the whole decode: slot offsets, and (after the barrier) channel values
@@ -742,6 +758,373 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
     }
 }
 
+// =======================================================================================================================
+// Min-sum (BP_MS) WITHOUT early termination on the same plan (BASELINE.json configs[2]).  The kernel is bound by the LDS:
+// four accesses per edge and iteration, the stores at a third of the loads' rate.  Here the 512 leaf edges of the n = 1024
+// code have no message slot at all (their check node's lane keeps the leaf's input LLR and its v2c message — the
+// reference's (L_ch + c2v) - c2v, decoder.cpp:58-62, which floating point does not make L_ch — in registers), the hard
+// decisions stay in registers, and the prologue is the balanced one.  Every operation is the reference's: sign * sign *
+// min (decoder.h:17-20: exact, so the order of a check node's inputs does not matter), the variable node's sum in column
+// file order, v2c = out - c2v.  LLR-out doubles == the reference's.
+template <int D, bool LEAF, bool TWO>
+__device__ __forceinline__ void cnms_call(char *msg, uint32_t off0, uint32_t off1, uint32_t cnt0, int lane, double &lv0, double &lv1,
+                                          double L0, double L1, double &out0, double &out1)
+{
+    constexpr int M = D - (LEAF ? 1 : 0);
+    const uint32_t stride = TWO ? kWaveSize * 8u : cnt0 * 8u;
+    char *p0 = msg + off0 + lane * 8, *p1 = msg + off1 + lane * 8;
+    double v0[D], v1[D];
+#pragma unroll
+    for (int k = 0; k < M; ++k)
+        v0[k] = *at(p0, k * stride);
+    if constexpr (TWO)
+    {
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+            v1[k] = *at(p1, k * stride);
+    }
+    if constexpr (LEAF)
+        v0[M] = lv0, v1[M] = lv1;
+    cn_core<D, true>(v0);
+    if constexpr (TWO)
+        cn_core<D, true>(v1);
+#pragma unroll
+    for (int k = 0; k < M; ++k)
+        *at(p0, k * stride) = v0[k];
+    if constexpr (TWO)
+    {
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+            *at(p1, k * stride) = v1[k];
+    }
+    if constexpr (LEAF) // the leaf's variable-node update (decoder.cpp:50-62 for a node of degree 1), by this lane
+    {
+        out0 = L0 + v0[M];
+        lv0 = out0 - v0[M];
+        if constexpr (TWO)
+        {
+            out1 = L1 + v1[M];
+            lv1 = out1 - v1[M];
+        }
+    }
+}
+
+__device__ __forceinline__ void vnms2_pair(char *msg, uint32_t packed_a, uint32_t packed_b, double La, double Lb, double &oa, double &ob)
+{
+    asm volatile("" : "+v"(packed_a), "+v"(packed_b)); // unpack here, every pass
+    const uint32_t a0 = packed_a & 0xFFFFu, a1 = packed_a >> 16, b0 = packed_b & 0xFFFFu, b1 = packed_b >> 16;
+    const double ca0 = *at(msg, a0), ca1 = *at(msg, a1), cb0 = *at(msg, b0), cb1 = *at(msg, b1);
+    oa = La + ca0, ob = Lb + cb0; // sequential sum in column file order (decoder.cpp:50-56)
+    oa += ca1, ob += cb1;
+    *at(msg, a0) = oa - ca0, *at(msg, a1) = oa - ca1;
+    *at(msg, b0) = ob - cb0, *at(msg, b1) = ob - cb1;
+}
+
+__device__ __forceinline__ double vnms2_one(char *msg, uint32_t packed_a, double La)
+{
+    asm volatile("" : "+v"(packed_a));
+    const uint32_t a0 = packed_a & 0xFFFFu, a1 = packed_a >> 16;
+    const double ca0 = *at(msg, a0), ca1 = *at(msg, a1);
+    double oa = La + ca0;
+    oa += ca1;
+    *at(msg, a0) = oa - ca0, *at(msg, a1) = oa - ca1;
+    return oa;
+}
+
+template <int DV>
+__device__ __forceinline__ double vnms_wide(char *msg, const uint32_t (&packed)[8], double L)
+{
+    uint32_t pk[(DV + 1) / 2];
+    auto opaque = [&] {
+#pragma unroll
+        for (int i = 0; i < (DV + 1) / 2; ++i)
+        {
+            pk[i] = packed[i];
+            asm volatile("" : "+v"(pk[i]));
+        }
+    };
+    auto slot = [&](int p) { return at(msg, (p & 1) ? pk[p >> 1] >> 16 : pk[p >> 1] & 0xFFFFu); };
+    opaque();
+    double c[DV];
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        c[p] = *slot(p);
+    double out = L;
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        out += c[p];
+    opaque();
+#pragma unroll
+    for (int p = 0; p < DV; ++p)
+        *slot(p) = out - c[p];
+    return out;
+}
+
+__device__ __forceinline__ double vnms_table(char *msg, const uint32_t *tbl, int lane, int count, int degree, double L)
+{
+    double out = L;
+    for (int p = 0; p < degree; ++p)
+        out += *at(msg, tbl[p * count + lane]);
+    for (int p = 0; p < degree; ++p)
+    {
+        double *m = at(msg, tbl[p * count + lane]);
+        *m = out - *m;
+    }
+    return out;
+}
+
+template <bool WANT_LLR, int VNB, int CNL>
+__device__ __forceinline__ void fused_ms_body(const DecodeArgs &a, const DevFusedPlan &F)
+{
+    extern __shared__ double lds[];
+    __shared__ int misc[4];
+    const DevPlan &P = a.plan;
+    const int nc = P.nc, nct = P.nct;
+    const uint64_t frame = blockIdx.x;
+    char *msg = reinterpret_cast<char *>(lds);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_amdgcn_s_setprio(LDPC_AMD_DECODE_PRIO);
+    const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
+    if (tid == 0)
+        misc[0] = 0;
+
+    // ---- prologue: the input LLRs, staged once (16-byte entries: the lane table's offsets are those of the ratio form) ----
+    const bool given = a.mode == kModeLlr;
+    const int n_stage = given ? nc : nct;
+    double2 *stage = reinterpret_cast<double2 *>(lds);
+    bool addressed = stage_channel(a, F, frame, tid, [&](int s, double L) { stage[s].x = L; });
+    if (tid == kThreads - 1)
+        stage[n_stage + 1].x = 0.0; // punctured, never written by the channel, no node
+    const uint32_t *tab = F.lane_tab + (static_cast<uint32_t>(wave) * kFusedLaneRows) * kWaveSize + lane;
+    const auto my_vdesc = uniform_table(F.vn_desc + wave * kFusedVnSlots * 4);
+    const uint32_t vn_prog = F.vn_prog[wave];
+    uint32_t my_idx[VNB], wide_idx[8], vn_entry[VNB], leaf_entry[2 * CNL];
+#pragma unroll
+    for (int w = 0; w < VNB; ++w)
+        my_idx[w] = tab[w * kWaveSize];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        wide_idx[i] = tab[(8 + i) * kWaveSize];
+    const uint32_t none_entry = static_cast<uint32_t>(n_stage + 1) * 16u;
+    auto entry_of = [&](int mode_row, int col_row) {
+        if (given)
+        {
+            const uint32_t cwd = tab[col_row * kWaveSize];
+            return cwd == kFusedNone ? none_entry : (cwd & 0x3FFFFFFFu) * 16u;
+        }
+        return tab[mode_row * kWaveSize];
+    };
+#pragma unroll
+    for (int w = 0; w < VNB; ++w)
+        vn_entry[w] = entry_of(16 + w, 24 + w);
+#pragma unroll
+    for (int c = 0; c < 2 * CNL; ++c)
+        leaf_entry[c] = entry_of(32 + c, 36 + c);
+    __syncthreads();
+    double my_L[VNB], leaf_L[2 * CNL], leaf_v2c[2 * CNL];
+#pragma unroll
+    for (int w = 0; w < VNB; ++w)
+        my_L[w] = *at(msg, vn_entry[w]);
+#pragma unroll
+    for (int c = 0; c < 2 * CNL; ++c)
+        leaf_L[c] = leaf_v2c[c] = *at(msg, leaf_entry[c]);
+    __syncthreads();
+    // v2c initialisation: decoder.cpp:16-19
+#pragma unroll
+    for (int w = 0; w < VNB; ++w)
+    {
+        const uint32_t d0 = my_vdesc[4 * w];
+        const int cnt = static_cast<int>(d0 & 0xFFFFu), deg = static_cast<int>(d0 >> 16);
+        if (lane >= cnt)
+            continue;
+        if (deg == 2)
+            *at(msg, my_idx[w] & 0xFFFFu) = my_L[w], *at(msg, my_idx[w] >> 16) = my_L[w];
+        else if (w == 0 && deg <= 15)
+        {
+#pragma unroll
+            for (int q = 0; q < 15; ++q)
+                if (q < deg)
+                    *at(msg, (wide_idx[q >> 1] >> (16 * (q & 1))) & 0xFFFFu) = my_L[w];
+        }
+        else
+        {
+            const uint32_t *idx = F.vn_slot + my_vdesc[4 * w + 1];
+            for (int p = 0; p < deg; ++p)
+                *at(msg, idx[p * cnt + lane]) = my_L[w];
+        }
+    }
+    __syncthreads();
+
+    const auto my_leaf_calls = uniform_table(reinterpret_cast<const uint32_t *>(F.leaf_calls + wave * kFusedLeafCalls));
+    const auto my_calls = uniform_table(reinterpret_cast<const uint32_t *>(F.calls + wave * F.calls_stride));
+    double *out_llr = WANT_LLR ? a.llr_out + frame * nc : nullptr;
+    uint32_t leaf_bits = 0, vn_bits = 0;
+    for (uint32_t I = 0; I < a.iterations; ++I)
+    {
+        const bool last = I + 1 == a.iterations;
+        auto leaf_calls_now = my_leaf_calls;
+        auto vdesc_now = my_vdesc;
+        uint32_t prog = vn_prog;
+        asm volatile("" : "+s"(leaf_calls_now), "+s"(vdesc_now), "+s"(prog)); // (see fused_body)
+        // ---- check-node pass: decoder.cpp:25-45 ----
+        uint32_t lbits = 0;
+#pragma unroll
+        for (int c = 0; c < CNL; ++c)
+        {
+            const uint32_t offs = leaf_calls_now[4 * c], cnts = leaf_calls_now[4 * c + 1], cls = leaf_calls_now[4 * c + 2];
+            const uint32_t cnt0 = cnts & 0xFFFFu;
+            if (cnt0 == 0)
+                continue;
+            const bool two = (cnts >> 16) != 0;
+            double o0 = 1.0, o1 = 1.0;
+#define LDPC_MS_LEAF(D)                                                                                                                   \
+    case D:                                                                                                                               \
+        if (two)                                                                                                                          \
+            cnms_call<D, true, true>(msg, offs & 0xFFFFu, offs >> 16, cnt0, lane, leaf_v2c[2 * c], leaf_v2c[2 * c + 1], leaf_L[2 * c],    \
+                                     leaf_L[2 * c + 1], o0, o1);                                                                          \
+        else if (lane < static_cast<int>(cnt0))                                                                                           \
+            cnms_call<D, true, false>(msg, offs & 0xFFFFu, 0, cnt0, lane, leaf_v2c[2 * c], leaf_v2c[2 * c + 1], leaf_L[2 * c],            \
+                                      leaf_L[2 * c + 1], o0, o1);                                                                         \
+        break;
+            switch (cls & 7u) // wave-uniform (a min-sum node does not care where its outputs go: degree and leaf only)
+            {
+                LDPC_MS_LEAF(3)
+                LDPC_MS_LEAF(4)
+            default: break;
+            }
+#undef LDPC_MS_LEAF
+            lbits |= (o0 <= 0 ? 1u : 0u) << (2 * c) | (o1 <= 0 ? 1u : 0u) << (2 * c + 1);
+            if constexpr (WANT_LLR)
+                if (last)
+                {
+                    if (const uint32_t cwd = tab[(36 + 2 * c) * kWaveSize]; cwd != kFusedNone)
+                        out_llr[cwd & 0x3FFFFFFFu] = o0;
+                    if (const uint32_t cwd = tab[(37 + 2 * c) * kWaveSize]; cwd != kFusedNone)
+                        out_llr[cwd & 0x3FFFFFFFu] = o1;
+                }
+        }
+        leaf_bits = lbits;
+        for (int c = 0; c < F.calls_stride; ++c)
+        {
+            const uint32_t offs = my_calls[4 * c], cnts = my_calls[4 * c + 1], cls = my_calls[4 * c + 2];
+            const uint32_t cnt0 = cnts & 0xFFFFu;
+            if (cnt0 == 0)
+                break;
+            const bool two = (cnts >> 16) != 0;
+            double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#define LDPC_MS(D)                                                                                                        \
+    case D:                                                                                                               \
+        if (two)                                                                                                          \
+            cnms_call<D, false, true>(msg, offs & 0xFFFFu, offs >> 16, cnt0, lane, d0, d1, 0.0, 0.0, d2, d3);             \
+        else if (lane < static_cast<int>(cnt0))                                                                           \
+            cnms_call<D, false, false>(msg, offs & 0xFFFFu, 0, cnt0, lane, d0, d1, 0.0, 0.0, d2, d3);                     \
+        break;
+            switch (cls & 7u)
+            {
+                LDPC_MS(2)
+                LDPC_MS(3)
+                LDPC_MS(4)
+            default: break;
+            }
+#undef LDPC_MS
+        }
+        __syncthreads();
+
+        // ---- variable-node pass, APP and hard decision: decoder.cpp:48-64 ----
+        uint32_t bits = 0;
+        [[maybe_unused]] auto put_llr = [&](int w, double llr) {
+            if constexpr (WANT_LLR)
+                if (last)
+                    out_llr[tab[(24 + w) * kWaveSize] & 0x3FFFFFFFu] = llr;
+        };
+        auto one = [&](int w, uint32_t kind) {
+            const uint32_t d0 = vdesc_now[4 * w];
+            const int cnt = static_cast<int>(d0 & 0xFFFFu), deg = static_cast<int>(d0 >> 16);
+            if (lane >= cnt)
+                return;
+            double out = 1.0;
+            if (kind == kFusedVnPair || kind == kFusedVn2)
+                out = vnms2_one(msg, my_idx[w], my_L[w]);
+            else if (w == 0 && kind == kFusedVnWide)
+                switch (deg) // wave-uniform
+                {
+#define LDPC_VN(DV) \
+    case DV: out = vnms_wide<DV>(msg, wide_idx, my_L[0]); break;
+                    LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8) LDPC_VN(9)
+                    LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15)
+#undef LDPC_VN
+                default: break;
+                }
+            else
+                out = vnms_table(msg, F.vn_slot + vdesc_now[4 * w + 1], lane, cnt, deg, my_L[w]);
+            bits |= (out <= 0 ? 1u : 0u) << w;
+            put_llr(w, out);
+        };
+#pragma unroll
+        for (int w = 0; w < VNB; w += 2)
+        {
+            const uint32_t k01 = (prog >> (4 * w)) & 0xFFu; // (wave-uniform)
+            if (w + 1 < VNB && k01 == (kFusedVnPair | (kFusedVnPair << 4)))
+            {
+                double oa, ob;
+                vnms2_pair(msg, my_idx[w], my_idx[w + 1], my_L[w], my_L[w + 1], oa, ob);
+                bits |= (oa <= 0 ? 1u : 0u) << w | (ob <= 0 ? 1u : 0u) << (w + 1);
+                put_llr(w, oa), put_llr(w + 1, ob);
+            }
+            else
+            {
+                if (k01 & 0xFu)
+                    one(w, k01 & 0xFu);
+                if (w + 1 < VNB && (k01 >> 4))
+                    one(w + 1, k01 >> 4);
+            }
+        }
+        vn_bits = bits;
+        __syncthreads();
+    }
+
+    // ---- outputs: iteration count (decoder.cpp:74-77: no early termination), hard decisions, bit errors (ldpcsim.cpp:184-188) ----
+    if (tid == 0 && a.iters)
+        a.iters[frame] = a.iterations;
+    uint8_t *hard = a.hard ? a.hard + frame * nc : nullptr;
+    int err = 0;
+    if (hard || a.bit_errors)
+    {
+        auto account = [&](uint32_t cwd, uint32_t bit) {
+            if (cwd == kFusedNone)
+                return;
+            const uint32_t col = cwd & 0x3FFFFFFFu;
+            if (hard)
+                hard[col] = static_cast<uint8_t>(bit);
+            if (cwd & kFusedCounted)
+                err += static_cast<int>(bit) != (cw ? static_cast<int>(cw[col]) : 0);
+        };
+#pragma unroll
+        for (int w = 0; w < VNB; ++w)
+            account(tab[(24 + w) * kWaveSize], (vn_bits >> w) & 1u);
+#pragma unroll
+        for (int c = 0; c < 2 * CNL; ++c)
+            account(tab[(36 + c) * kWaveSize], (leaf_bits >> c) & 1u);
+    }
+    if (a.bit_errors)
+    {
+        err = wave_sum(err);
+        if (lane == 0 && err)
+            atomicAdd(&misc[0], err);
+        __syncthreads();
+        if (tid == 0)
+            a.bit_errors[frame] = addressed ? static_cast<uint32_t>(misc[0]) : 0xFFFFFFFFu;
+    }
+}
+
+template <bool WANT_LLR, int VNB, int CNL>
+__global__ __launch_bounds__(kThreads) void decode_fused_ms_kernel(const DecodeArgs a, const DevFusedPlan f)
+{
+    fused_ms_body<WANT_LLR, VNB, CNL>(a, f);
+}
+
 // the instantiation of the n = 1024 code (at most four variable-node blocks and one leaf call per wave, no LLR output) is
 // compiled for LDPC_AMD_FUSED_WAVES waves per SIMD = that many frames per CU (its messages take 23 KB of LDS)
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(LDPC_AMD_FUSED_WAVES, LDPC_AMD_FUSED_WAVES))) void
@@ -772,6 +1155,27 @@ int launch_decode_fused(const DecodeArgs &a, const DevFusedPlan &f, void *stream
         k = (want_llr || !f.wide_exclusive) ? (want_llr ? decode_fused_kernel<true, 4, 1> : decode_fused_kernel<false, 4, 1>) : decode_fused_small;
     else
         k = want_llr ? decode_fused_kernel<true, kFusedVnSlots, kFusedLeafCalls> : decode_fused_kernel<false, kFusedVnSlots, kFusedLeafCalls>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(f.lds_bytes));
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(a.n_frames)), dim3(kThreads), f.lds_bytes, static_cast<hipStream_t>(stream), a, f);
+    return hipGetLastError();
+}
+
+int launch_decode_fused_minsum(const DecodeArgs &a, const DevFusedPlan &f, void *stream)
+{
+    if (a.n_frames == 0)
+        return hipSuccess;
+    if (a.early_term || a.iterations == 0 || a.redo_list || a.redo_count_in)
+        return hipErrorInvalidValue;
+    if (f.vnb > kFusedVnSlots || f.cnl > kFusedLeafCalls)
+        return hipErrorInvalidValue;
+    const bool want_llr = a.llr_out != nullptr;
+    void (*k)(const DecodeArgs, const DevFusedPlan) = nullptr;
+    if (f.vnb <= 4 && f.cnl <= 1)
+        k = want_llr ? decode_fused_ms_kernel<true, 4, 1> : decode_fused_ms_kernel<false, 4, 1>;
+    else
+        k = want_llr ? decode_fused_ms_kernel<true, kFusedVnSlots, kFusedLeafCalls> : decode_fused_ms_kernel<false, kFusedVnSlots, kFusedLeafCalls>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(f.lds_bytes));
     if (e != hipSuccess)
         return e;

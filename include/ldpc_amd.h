@@ -215,6 +215,9 @@ void ldpc_hip_comm_destroy(ldpc_hip_comm *comm);
    bound: when a rank does not arrive within LDPC_AMD_COMM_TIMEOUT_S seconds (default 60; ncclCommInitRank in
    ldpc_hip_comm_create likewise) the call fails on the ranks that wait for it and the communicator is unusable from then on */
 int ldpc_hip_comm_allgather(ldpc_hip_comm *comm, const void *send, void *recv, uint64_t bytes);
+/* the steps of the layered schedule of the non-parity modes 2 / 3 (host only): step_of_row[mc] = the step each check node
+   is processed in; returns the number of steps, -1 when the schedule does not take the code */
+int ldpc_hip_selftest_layer_plan(ldpc_hip_ctx *ctx, int32_t *step_of_row);
 /* the placement step of ldpc_hip_stream_decode_sharded by itself, without a GPU (tests): this rank reports {pairs in its
    piece, pairs including the margin, status}; after the all-gather over `comm` out = {first frame, frames of this rank,
    frames of the step, stream index of the piece's first pair, stream index of the first pair after the step}.  A non-zero

@@ -91,6 +91,8 @@ def load_library(path=LIB_PATH):
     L.ldpc_hip_comm_destroy.argtypes = [vp]
     L.ldpc_hip_comm_allgather.restype = i32
     L.ldpc_hip_comm_allgather.argtypes = [vp, vp, vp, u64]
+    L.ldpc_hip_selftest_layer_plan.restype = i32
+    L.ldpc_hip_selftest_layer_plan.argtypes = [vp, vp]
     L.ldpc_hip_selftest_place.restype = i32
     L.ldpc_hip_selftest_place.argtypes = [vp, u64, u64, u64, u64, u64, u64, u64, vp]
     L.ldpc_hip_comm_stats.restype = None

@@ -570,6 +570,21 @@ int ldpc_hip_comm_allgather(ldpc_hip_comm *comm, const void *send, void *recv, u
     return guarded([&] { comm->comm->all_gather(send, recv, bytes); });
 }
 
+int ldpc_hip_selftest_layer_plan(ldpc_hip_ctx *ctx, int32_t *step_of_row)
+{
+    int n = -1;
+    if (guarded([&] {
+            const LayerPlan L = build_layer_plan(ctx->eng->code(), ctx->eng->plan());
+            if (!L.ok)
+                throw std::runtime_error("the layered schedule does not take this code");
+            for (size_t i = 0; i < L.step_of_row.size(); ++i)
+                step_of_row[i] = L.step_of_row[i];
+            n = static_cast<int>(L.steps.size());
+        }) != 0)
+        return -1;
+    return n;
+}
+
 int ldpc_hip_selftest_place(ldpc_hip_comm *comm, uint64_t nct, uint64_t pairs_before, uint64_t frame_pos, uint64_t cap,
                             uint64_t piece_pairs, uint64_t pairs_with_margin, uint64_t status, uint64_t out[5])
 {

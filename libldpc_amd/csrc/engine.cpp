@@ -1087,6 +1087,7 @@ void Engine::stream_begin(int channel, uint64_t seed, double x, bool fresh)
     frame_pos_ = 0;
     raw_next_ = 0;
     cur_pair_ = cur_chunk_ = cur_k_ = 0;
+    small_cache_.valid = false;
     sh_chunk_ = sh_pairs_ = 0;
     stream_mode_ = 0;
     noise_.reset(seed);
@@ -1219,14 +1220,6 @@ void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream, bool write_no
     hipStream_t user = static_cast<hipStream_t>(stream);
     ensure_rng_stream();
     hipStream_t s = static_cast<hipStream_t>(rng_stream_);
-    const int buf = pp_;
-    if (write_normals)
-    {
-        pp_ ^= 1;
-        // the decode kernel that last read this slab buffer (two batches ago) must be done before it is refilled
-        if (pairs_in_use_[buf])
-            check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev_pairs_free_[buf]), 0), "wait pairs free");
-    }
     const uint64_t nct = static_cast<uint64_t>(plan_.nct);
     const uint64_t g0 = frame_pos_ * nct, g1 = g0 + n * nct; // normals [g0, g1)
     const uint64_t q0 = g0 >> 1, q1 = (g1 - 1) >> 1, qn = g1 >> 1;
@@ -1234,8 +1227,35 @@ void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream, bool write_no
         throw std::runtime_error("noise stream out of step");
     // pairs that must exist from the start of chunk cur_chunk_ on / list index of the first pair the NEXT batch needs
     const uint64_t need = cur_k_ + (q1 - q0 + 1), target = cur_k_ + (qn - q0);
+    if (write_normals && small_cache_.valid && small_cache_.chunk == cur_chunk_ && need <= small_cache_.np.res.total &&
+        target < small_cache_.np.res.total && !std::getenv("LDPC_AMD_NO_SMALL_CACHE"))
+    {
+        // (the slab was complete when the pass that made it returned, and the decode launches that read it since are
+        // ordered on the caller's stream by the events of run_decode as for any batch)
+        check(hipStreamWaitEvent(user, static_cast<hipEvent_t>(ev_pairs_ready_[small_cache_.buf]), 0), "wait pairs ready");
+        fill_slab_args(a, small_cache_.np, q0 - cur_k_, small_cache_.buf);
+        a.normal_base = g0;
+        cur_k_ = target;
+        cur_pair_ = qn;
+        return;
+    }
+    const int buf = pp_;
+    if (write_normals)
+    {
+        pp_ ^= 1;
+        if (small_cache_.buf == buf)
+            small_cache_.valid = false;
+        // the decode kernel that last read this slab buffer (two batches ago) must be done before it is refilled
+        if (pairs_in_use_[buf])
+            check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev_pairs_free_[buf]), 0), "wait pairs free");
+    }
     const uint64_t ct = noise_.st.chunk_trials();
     double trials = static_cast<double>(need) * 1.2732395447351628 + 8.0 * std::sqrt(static_cast<double>(need)) + 256;
+    // a small request: two dozen frames further than asked (a fraction of the prefix's serial chain), for the requests
+    // that are likely to follow (small_cache_)
+    const bool small = write_normals && n <= 16;
+    if (small)
+        trials += 24.0 * static_cast<double>(nct / 2 + 1) * 1.2732395447351628;
     NoisePass np;
     PhaseTrace tr;
     prof_mark(1, s);
@@ -1260,6 +1280,11 @@ void Engine::awgn_prepare(uint64_t n, DecodeArgs &a, void *stream, bool write_no
         check(hipStreamWaitEvent(user, static_cast<hipEvent_t>(ev_pairs_ready_[buf]), 0), "wait pairs ready");
         fill_slab_args(a, np, q0 - cur_k_, buf);
         a.normal_base = g0;
+    }
+    if (write_normals)
+    {
+        small_cache_.valid = small && np.n_slabs == 1 && np.res.next_slab == 0;
+        small_cache_.chunk = cur_chunk_, small_cache_.buf = buf, small_cache_.np = np;
     }
     cur_chunk_ += np.res.next_slab;
     cur_k_ = np.res.next_k;
@@ -1515,6 +1540,8 @@ Engine::ShardStep Engine::stream_decode_sharded(Comm &comm, const DecParams &p, 
             hipStream_t s = static_cast<hipStream_t>(rng_stream_);
             buf = pp_;
             pp_ ^= 1;
+            if (small_cache_.buf == buf)
+                small_cache_.valid = false;
             if (pairs_in_use_[buf])
                 check(hipStreamWaitEvent(s, static_cast<hipEvent_t>(ev_pairs_free_[buf]), 0), "wait pairs free");
             prof_mark(1, s);

@@ -240,6 +240,16 @@ class Engine
         uint64_t *slabs = nullptr, *cum = nullptr;
         NormalsResult res{};
     };
+    // Small requests in a row (one frame at a time: the reference's own call pattern) — the last single-chunk pass is kept:
+    // it was generated a few frames further than asked, and while the following requests fall inside it they take their
+    // normals from the slab that is already there instead of regenerating their chunk's prefix from its start
+    struct SmallCache
+    {
+        bool valid = false;
+        uint64_t chunk = 0;
+        int buf = 0;
+        NoisePass np;
+    } small_cache_;
     NoisePass noise_pass(uint64_t chunk, uint32_t full, uint32_t last_blocks, uint32_t n_piece, uint64_t need, uint64_t target, int buf,
                          bool write_normals, bool strided, uint64_t stride);
     void fill_slab_args(DecodeArgs &a, const NoisePass &np, uint64_t pair_origin, int buf) const;

@@ -299,7 +299,11 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
             if (RATIO && (v & 2u)) // checked before the syndrome: an escaped frame's decisions mean nothing
             {
                 if (tid == 0)
-                    a.redo_list[atomicAdd(a.redo_count, 1u)] = static_cast<uint32_t>(frame);
+                {
+                    uint32_t fr = static_cast<uint32_t>(frame); // (taken from the scalar register here: a vector copy made before
+                    asm volatile("" : "+s"(fr));                 // the loop would be spilled across it)
+                    a.redo_list[atomicAdd(a.redo_count, 1u)] = fr;
+                }
                 return;
             }
             if (I > 0 && a.early_term && !(v & 1u)) // decoder.cpp:66-72: the decisions of iteration I-1 are a codeword
@@ -528,6 +532,9 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
     }
 #endif
     // ---- outputs ----
+    // (the thread index afresh: offsets derived from it before the loop would be held — spilled — across the whole decode)
+    int tid_out = tid;
+    asm volatile("" : "+v"(tid_out));
     const bool ran = a.iterations > 0;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -551,19 +558,19 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
     if (a.hard)
     {
         uint8_t *h = a.hard + frame * nc;
-        for (int r = tid; r < nc; r += NT)
+        for (int r = tid_out; r < nc; r += NT)
             h[P.rank_col[r]] = hard[r];
     }
     if constexpr (WANT_LLR)
     {
         if (!ran)
-            for (int r = tid; r < nc; r += NT)
+            for (int r = tid_out; r < nc; r += NT)
                 out_llr[P.rank_col[r]] = 0.0;
     }
     if (a.bit_errors)
     {
         int err = 0;
-        for (int i = tid; i < P.n_bitpos; i += NT)
+        for (int i = tid_out; i < P.n_bitpos; i += NT)
         {
             int est = hard[P.tx_rank[i]];
             int tx = cw ? static_cast<int>(cw[P.bit_pos[i]]) : 0;

@@ -793,6 +793,10 @@ LayerPlan build_layer_plan(const LdpcCode &code, const Plan &plan)
         for (int p = H.rptr[i]; p < H.rptr[i + 1]; ++p)
             dst->used[H.rcol[p]] = 1;
     }
+    L.step_of_row.assign(H.rows, -1);
+    for (size_t si = 0; si < open.size(); ++si)
+        for (int i : open[si].rows)
+            L.step_of_row[i] = static_cast<int>(si);
     for (const Open &o : open)
     {
         LayerStep st{static_cast<uint32_t>(L.vn.size()), static_cast<uint16_t>(o.rows.size()), static_cast<uint16_t>(o.degree)};

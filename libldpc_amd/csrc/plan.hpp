@@ -184,6 +184,7 @@ struct LayerPlan
     std::vector<LayerStep> steps;
     std::vector<uint16_t> vn;
     uint32_t slots = 0; // entries of the message array (sum of 64 * degree over the steps)
+    std::vector<int> step_of_row; // (tests: the step each check node is processed in)
 };
 LayerPlan build_layer_plan(const LdpcCode &code, const Plan &plan);
 

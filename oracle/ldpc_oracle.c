@@ -1024,6 +1024,270 @@ int orc_decode(const orc_code *c, int min_sum, int early_term, unsigned iteratio
     return it;
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* Mirrors of the opt-in NON-PARITY modes (libldpc_amd/csrc/kernels_fast.hip,     */
+/* kernels_layered.hip).  Nothing here is the reference's algorithm — the reference has neither     */
+/* binary32 messages nor a layered schedule — so there is no fixture to pin these against; they     */
+/* restate, independently and in plain C with libm's exp2f / log2f and an IEEE 1.0f / x where the   */
+/* kernels use v_exp_f32 / v_log_f32 / v_rcp_f32, the schedule and the arithmetic the kernels claim */
+/* to implement.  The hardware instructions are accurate to about one ulp, not correctly rounded:   */
+/* tests compare with tolerances (same iteration / sweep counts and decisions on >= 99.9 % of the   */
+/* frames, LLRs to 1e-3 relative on converged frames), never bit for bit.                           */
+/* ------------------------------------------------------------------------------------------------ */
+#define FAST_CLIP 40.0f
+#define FAST_LOG2E 1.4426950408889634f
+static inline float fclip(float x) { return fminf(fmaxf(x, -FAST_CLIP), FAST_CLIP); }
+static inline float f_lambda(float a, float b) { return (a + b) * (1.0f / fmaf(a, b, 1.0f)); }
+static inline float f_rho(float a, float b) { return fmaf(a, b, 1.0f) * (1.0f / (a + b)); }
+
+/* check node on D likelihood ratios v[] (rho = 2^L2): lambda(c2v_j) out, forward/backward order of decoder.cpp:31-44 */
+static void fast_cn(int D, const float *v, float *o)
+{
+    float F[64], B[64];
+    if (D == 2)
+    {
+        o[0] = 1.0f / v[1], o[1] = 1.0f / v[0];
+        return;
+    }
+    F[0] = v[0], B[D - 1] = v[D - 1];
+    for (int j = 1; j <= D - 3; ++j)
+        F[j] = f_rho(F[j - 1], v[j]);
+    for (int j = D - 2; j >= 2; --j)
+        B[j] = f_rho(B[j + 1], v[j]);
+    o[0] = f_lambda(D > 3 ? B[2] : v[2], v[1]);
+    o[D - 1] = f_lambda(D > 3 ? F[D - 3] : v[0], v[D - 2]);
+    for (int j = 1; j < D - 1; ++j)
+        o[j] = f_lambda(F[j - 1], B[j + 1]);
+}
+
+/* mode 1: flooding sum-product, binary32 messages (v2c as rho = 2^L2 with the sender's decision in the sign, c2v as
+   lambda = 2^-L2), L2 = LLR in log2 units clipped to +-40; the variable node sums log2 values */
+static int dec_decode_fast32(const orc_code *c, int early_term, unsigned iterations, const double *llr_in, double *llr_out, uint8_t *hard)
+{
+    const spm *H = &c->H;
+    const int nc = H->cols, nnz = H->nnz;
+    float *msg = malloc(4 * (size_t)(nnz > 0 ? nnz : 1)), *l2 = malloc(4 * (size_t)nc);
+    uint8_t *dec = calloc((size_t)nnz + 1, 1), *co = calloc((size_t)nc, 1);
+    for (int i = 0; i < nc; ++i)
+    {
+        l2[i] = fclip((float)llr_in[i] * FAST_LOG2E);
+        for (int p = H->cptr[i]; p < H->cptr[i + 1]; ++p)
+            msg[H->cedge[p]] = exp2f(l2[i]), dec[H->cedge[p]] = 0;
+        if (llr_out)
+            llr_out[i] = 0.0;
+    }
+    unsigned I = 0;
+    for (;;)
+    {
+        int bad = 0;
+        for (int i = 0; i < H->rows; ++i)
+        {
+            const int cw = H->rptr[i + 1] - H->rptr[i];
+            const int *cn = H->redge + H->rptr[i];
+            float v[64], o[64];
+            int par = 0;
+            for (int j = 0; j < cw; ++j)
+                v[j] = msg[cn[j]], par ^= dec[cn[j]];
+            bad |= par;
+            fast_cn(cw, v, o);
+            for (int j = 0; j < cw; ++j)
+                msg[cn[j]] = o[j];
+        }
+        if (I > 0 && early_term && !bad)
+        {
+            --I;
+            break;
+        }
+        if (I == iterations)
+            break;
+        for (int i = 0; i < nc; ++i)
+        {
+            const int deg = H->cptr[i + 1] - H->cptr[i];
+            float cl[64], tot = l2[i];
+            for (int k = 0; k < deg; ++k)
+            {
+                cl[k] = log2f(msg[H->cedge[H->cptr[i] + k]]);
+                tot -= cl[k];
+            }
+            co[i] = (uint8_t)(tot <= 0.0f);
+            if (llr_out)
+                llr_out[i] = (double)tot * 0.6931471805599453;
+            for (int k = 0; k < deg; ++k)
+            {
+                const int e = H->cedge[H->cptr[i] + k];
+                msg[e] = exp2f(fclip(tot + cl[k]));
+                dec[e] = co[i];
+            }
+        }
+        ++I;
+    }
+    if (hard)
+        for (int i = 0; i < nc; ++i)
+            hard[i] = iterations > 0 ? co[i] : 0;
+    free(msg), free(l2), free(dec), free(co);
+    return (int)I;
+}
+
+/* binary32 -> binary16 -> binary32, round to nearest even (what a store of a _Float16 message and its reload do); |x| <= 40 */
+static float through_half(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t sign = u & 0x80000000u;
+    uint32_t a = u & 0x7FFFFFFFu;
+    float r;
+    if (a < 0x38800000u) /* below 2^-14: a binary16 subnormal, multiples of 2^-24 */
+    {
+        float ax;
+        memcpy(&ax, &a, 4);
+        const float q = ax * 16777216.0f; /* exact scaling; rintf rounds to nearest even */
+        r = rintf(q) * (1.0f / 16777216.0f);
+    }
+    else
+    {
+        const uint32_t keep = a & 0xFFFFE000u, rest = a & 0x1FFFu; /* 13 bits dropped */
+        uint32_t o = keep;
+        if (rest > 0x1000u || (rest == 0x1000u && (keep & 0x2000u)))
+            o += 0x2000u;
+        memcpy(&r, &o, 4);
+    }
+    uint32_t ru;
+    memcpy(&ru, &r, 4);
+    ru |= sign;
+    memcpy(&r, &ru, 4);
+    return r;
+}
+
+/* Steps of the layered schedule (libldpc_amd/csrc/plan.cpp, build_layer_plan, restated): rows in file order, each put
+   into the first step of its degree that has a free lane (64 per step) and none of its variable nodes yet; steps in the
+   order they were opened.  step_of[row] = step index; returns the number of steps. */
+int orc_layer_steps(const orc_code *c, int *step_of)
+{
+    const spm *H = &c->H;
+    int n_steps = 0, cap = 16;
+    int *deg = malloc(sizeof(int) * cap), *cnt = malloc(sizeof(int) * cap);
+    uint8_t **used = malloc(sizeof(uint8_t *) * cap);
+    for (int i = 0; i < H->rows; ++i)
+    {
+        const int d = H->rptr[i + 1] - H->rptr[i];
+        int dst = -1;
+        for (int s = 0; s < n_steps && dst < 0; ++s)
+        {
+            if (deg[s] != d || cnt[s] >= 64)
+                continue;
+            int clash = 0;
+            for (int p = H->rptr[i]; p < H->rptr[i + 1] && !clash; ++p)
+                clash = used[s][H->rnode[p]] != 0;
+            if (!clash)
+                dst = s;
+        }
+        if (dst < 0)
+        {
+            if (n_steps == cap)
+            {
+                cap *= 2;
+                deg = realloc(deg, sizeof(int) * cap), cnt = realloc(cnt, sizeof(int) * cap);
+                used = realloc(used, sizeof(uint8_t *) * cap);
+            }
+            dst = n_steps++;
+            deg[dst] = d, cnt[dst] = 0, used[dst] = calloc((size_t)H->cols, 1);
+        }
+        ++cnt[dst];
+        step_of[i] = dst;
+        for (int p = H->rptr[i]; p < H->rptr[i + 1]; ++p)
+            used[dst][H->rnode[p]] = 1;
+    }
+    for (int s = 0; s < n_steps; ++s)
+        free(used[s]);
+    free(used), free(deg), free(cnt);
+    return n_steps;
+}
+
+/* modes 2 / 3: layered (row-serial) sum-product, binary32 totals, binary32 (half = 0) or binary16 (half = 1) check-to-
+   variable messages in log2 units; returns the sweeps completed before the sweep whose syndrome check passed */
+static int dec_decode_layered(const orc_code *c, int half, int early_term, unsigned iterations, const double *llr_in, double *llr_out,
+                              uint8_t *hard)
+{
+    const spm *H = &c->H;
+    const int nc = H->cols, mc = H->rows;
+    int *step_of = malloc(sizeof(int) * (size_t)(mc > 0 ? mc : 1));
+    const int n_steps = orc_layer_steps(c, step_of);
+    /* rows in processing order: step by step (the order inside a step does not matter: its rows share no variable node) */
+    int *order = malloc(sizeof(int) * (size_t)(mc > 0 ? mc : 1)), k = 0;
+    for (int s = 0; s < n_steps; ++s)
+        for (int i = 0; i < mc; ++i)
+            if (step_of[i] == s)
+                order[k++] = i;
+    float *tot = malloc(4 * (size_t)nc), *c2v = calloc((size_t)(H->nnz > 0 ? H->nnz : 1), 4);
+    for (int i = 0; i < nc; ++i)
+        tot[i] = fclip((float)llr_in[i] * FAST_LOG2E);
+    unsigned I = 0;
+    while (I < iterations)
+    {
+        for (int q = 0; q < mc; ++q)
+        {
+            const int i = order[q], cw = H->rptr[i + 1] - H->rptr[i];
+            const int *cn = H->redge + H->rptr[i], *col = H->rnode + H->rptr[i];
+            float t[64], v[64], o[64];
+            for (int j = 0; j < cw; ++j)
+            {
+                t[j] = tot[col[j]] - c2v[cn[j]];
+                v[j] = exp2f(fclip(t[j]));
+            }
+            fast_cn(cw, v, o);
+            for (int j = 0; j < cw; ++j)
+            {
+                float m = fclip(0.0f - log2f(o[j]));
+                if (half)
+                    m = through_half(m);
+                c2v[cn[j]] = m;
+                tot[col[j]] = t[j] + m;
+            }
+        }
+        if (early_term)
+        {
+            int bad = 0;
+            for (int i = 0; i < mc && !bad; ++i)
+            {
+                int par = 0;
+                for (int p = H->rptr[i]; p < H->rptr[i + 1]; ++p)
+                    par ^= tot[H->rnode[p]] <= 0.0f;
+                bad |= par;
+            }
+            if (!bad)
+                break;
+        }
+        ++I;
+    }
+    for (int i = 0; i < nc; ++i)
+    {
+        if (hard)
+            hard[i] = iterations > 0 ? (uint8_t)(tot[i] <= 0.0f) : 0;
+        if (llr_out)
+            llr_out[i] = iterations > 0 ? (double)tot[i] * 0.6931471805599453 : 0.0;
+    }
+    free(step_of), free(order), free(tot), free(c2v);
+    return (int)I;
+}
+
+/* n frames (llr_in[n][nc], column order) through the mirror of fast mode `mode` (1: flooding binary32, 2: layered binary32,
+   3: layered binary16 messages), OpenMP over frames */
+void orc_decode_fast_batch(const orc_code *c, int mode, int early_term, unsigned iterations, uint64_t n, const double *llr_in,
+                           uint32_t *iters, double *llr_out, uint8_t *hard)
+{
+    const size_t nc = (size_t)c->H.cols;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (uint64_t f = 0; f < n; ++f)
+    {
+        double *lo = llr_out ? llr_out + f * nc : NULL;
+        uint8_t *hd = hard ? hard + f * nc : NULL;
+        const int it = mode == 1 ? dec_decode_fast32(c, early_term, iterations, llr_in + f * nc, lo, hd)
+                                 : dec_decode_layered(c, mode == 3, early_term, iterations, llr_in + f * nc, lo, hd);
+        if (iters)
+            iters[f] = (uint32_t)it;
+    }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* BEC decoder (decoder.h:130-156, decoder.cpp:91-192)                                   */
 /* ------------------------------------------------------------------------------------ */

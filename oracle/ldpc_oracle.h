@@ -65,6 +65,12 @@ int orc_rank(const orc_code *c); /* GF(2) rank of H (dense elimination; value ==
 /* ---- stand-alone decoders: decoder.cpp:11-78 and :91-192 ---- */
 int orc_decode(const orc_code *c, int min_sum, int early_term, unsigned iterations, int math_mode,
                const double *llr_in, double *llr_out, uint8_t *hard);
+/* mirrors of the opt-in NON-PARITY modes of the HIP library (1: flooding sum-product with binary32 messages, 2 / 3: layered
+   schedule with binary32 / binary16 messages): n frames of given LLRs; tolerance comparisons only (see the .c file) */
+void orc_decode_fast_batch(const orc_code *c, int mode, int early_term, unsigned iterations, uint64_t n, const double *llr_in,
+                           uint32_t *iters, double *llr_out, uint8_t *hard);
+/* step_of[row] = the step of the layered schedule the row is processed in; returns the number of steps */
+int orc_layer_steps(const orc_code *c, int *step_of);
 int orc_decode_bec(const orc_code *c, int early_term, unsigned iterations, int deg1_compat,
                    const uint8_t *llr_in, const uint8_t *codeword, uint8_t *llr_out, uint8_t *hard);
 

@@ -51,6 +51,10 @@ def lib():
     L.orc_rank.restype, L.orc_rank.argtypes = i32, [vp]
     L.orc_decode.restype = i32
     L.orc_decode.argtypes = [vp, i32, i32, u32, i32, vp, vp, vp]
+    L.orc_decode_fast_batch.restype = None
+    L.orc_decode_fast_batch.argtypes = [vp, i32, i32, u32, u64, vp, vp, vp, vp]
+    L.orc_layer_steps.restype = i32
+    L.orc_layer_steps.argtypes = [vp, vp]
     L.orc_decode_bec.restype = i32
     L.orc_decode_bec.argtypes = [vp, i32, u32, i32, vp, vp, vp, vp]
     L.orc_chan_new.restype = vp
@@ -127,6 +131,19 @@ class Code:
         hard = np.zeros(self.nc, np.uint8)
         it = lib().orc_decode(self.h, int(min_sum), int(early_term), iters, math, _p(llr_in), _p(out), _p(hard))
         return it, out, hard
+
+    def decode_fast(self, mode, llr_in, early_term=True, iters=50):
+        """Mirror of the HIP library's NON-PARITY mode `mode` (1, 2, 3) on frames llr_in[n][nc]: (iters, llr_out, hard)."""
+        x = np.ascontiguousarray(llr_in, np.float64).reshape(-1, self.nc)
+        n = x.shape[0]
+        it, out, hard = np.zeros(n, np.uint32), np.zeros((n, self.nc), np.float64), np.zeros((n, self.nc), np.uint8)
+        lib().orc_decode_fast_batch(self.h, int(mode), int(early_term), iters, n, _p(x), _p(it), _p(out), _p(hard))
+        return it, out, hard
+
+    def layer_steps(self):
+        step_of = np.zeros(self.mc, np.int32)
+        n = lib().orc_layer_steps(self.h, _p(step_of))
+        return n, step_of
 
     def decode_bec(self, llr_in, codeword, early_term=True, iters=50, compat=False):
         llr_in = np.ascontiguousarray(llr_in, np.uint8)

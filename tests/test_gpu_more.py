@@ -460,3 +460,33 @@ def test_layered_modes_are_opt_in_and_decode(mode, name):
             assert not code.syndrome(few["hard"][f]).any(), (name, f)
             assert np.array_equal(few["hard"][f], (few["llr_out"][f] <= 0).astype(np.uint8)), (name, f)
     assert (few["bit_errors"][few["iters"] < 50] == 0).all()
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_non_parity_modes_against_their_mirror(mode):
+    """SURVEY §8f item 4 / round-3 VERDICT #6: the three NON-PARITY modes against an independent plain-C restatement of the
+    schedule and arithmetic they claim to implement (oracle/ldpc_oracle.c: flooding with binary32 messages; the layered
+    sweep over the steps of build_layer_plan with binary32 / binary16 messages) on the same 16 384 frames of input LLRs.
+    The kernels use v_rcp_f32 / v_log_f32 / v_exp_f32 (about one ulp, not correctly rounded), the mirror IEEE division and
+    libm: a frame near a decision boundary may take a pass more or less, so the comparison is a tolerance — iteration /
+    sweep counts and hard decisions identical on at least 99.9 % of the frames; of the frames the mirror converges on, at
+    least 99.9 % with the same count, the same decisions AND every LLR-out within 1e-3 (relative to the larger of the value
+    and 1; the median frame agrees to 1e-5) — never the headline, never a parity claim."""
+    import libldpc_amd
+    code = orc.Code(orc.H_TXT)
+    d = libldpc_amd.HipDecoder(orc.H_TXT)
+    n = 16384
+    d.set_fast_mode(mode)
+    d.stream_begin("AWGN", 0, -4.0)
+    got = d.stream_decode(n, want=("iters", "hard", "llr_out", "llr_in"))
+    d.set_fast_mode(0)
+    it, llr, hard = code.decode_fast(mode, got["llr_in"])
+    same_it = got["iters"] == it
+    same_hard = (got["hard"] == hard).all(axis=1)
+    assert same_it.mean() >= 0.999, (mode, same_it.mean())
+    assert (same_it & same_hard).mean() >= 0.999, (mode, same_hard.mean())
+    conv = it < 50
+    err = (np.abs(got["llr_out"] - llr) / np.maximum(np.abs(llr), 1.0)).max(axis=1)  # per frame
+    good = same_it & same_hard & (err < 1e-3)
+    assert conv.mean() > 0.99 and good[conv].mean() >= 0.999, (mode, conv.mean(), good[conv].mean(), np.sort(err[conv])[-5:])
+    assert np.median(err[conv]) < 1e-5, (mode, np.median(err[conv]))

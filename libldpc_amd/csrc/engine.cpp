@@ -661,6 +661,7 @@ void Engine::upload_plan()
         dev_fused_.vn_desc = static_cast<const uint32_t *>(up(f.vn_desc.data(), f.vn_desc.size() * 4));
         dev_fused_.vn_slot = static_cast<const uint32_t *>(up(f.vn_slot.data(), f.vn_slot.size() * 4));
         dev_fused_.lane_tab = static_cast<const uint32_t *>(up(f.lane_tab.data(), f.lane_tab.size() * 4));
+        dev_fused_.ho_map = static_cast<const uint32_t *>(up(f.ho_map.data(), f.ho_map.size() * 4));
     }
     if (code_->has_G())
     {
@@ -774,10 +775,18 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         st.flush(s, &pin_out_);
         return;
     }
+    bool fused_handover_used = false;
     const auto launch = [&] {
         // the first launch of sum-product with early termination, for codes the fused form takes (fused_rule.h)
         if (fused_plan_.ok && !p.min_sum && p.early_term && a.redo_list && !a.redo_count_in && !a.ratio_separate)
             check(launch_decode_fused(a, dev_fused_, s), "decode (fused form)");
+        else if (fused_plan_.ok && !p.min_sum && !p.early_term && a.redo_list && a.redo_iter && !a.redo_count_in && !std::getenv("LDPC_AMD_NO_FUSED_HO"))
+        {
+            // without early termination: the fused form with separately divided outputs until a frame's totals near the edge
+            // of the box, then the LLR-domain launch below continues it (the messages are handed over as LLRs)
+            check(launch_decode_fused_handover(a, dev_fused_, s), "decode (fused form, hand-over)");
+            fused_handover_used = true;
+        }
         else if (fused_plan_.ok && p.min_sum && !p.early_term && p.iterations > 0 && !a.redo_list && !a.redo_count_in &&
                  !std::getenv("LDPC_AMD_NO_FUSED_MS"))
             check(launch_decode_fused_minsum(a, dev_fused_, s), "decode (min-sum, fused plan)");
@@ -891,7 +900,10 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         if (!later_stages)
             ;
         else if (handover)
+        {
             a.redo_iter_in = redo + 1 + n;
+            a.handover_llr = fused_handover_used ? 1 : 0;
+        }
         else if (plan_.lds_ok)
         {
             // The first launch ran the shared-reciprocal check nodes (detmath.h), whose denominator products leave their
@@ -911,7 +923,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
     }
     if (later_stages)
         launch();
-    a.redo_count_in = nullptr, a.redo_list_in = nullptr, a.redo_iter_in = nullptr, a.ws_handover = nullptr;
+    a.redo_count_in = nullptr, a.redo_list_in = nullptr, a.redo_iter_in = nullptr, a.ws_handover = nullptr, a.handover_llr = 0;
     prof_mark(0, s);
     if (a.mode == kModeAwgn && a.pairs_buffer >= 0 && ev_pairs_free_[a.pairs_buffer])
     {

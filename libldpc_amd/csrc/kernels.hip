@@ -1244,7 +1244,8 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     {
         const double *src = a.ws_handover + static_cast<uint64_t>(blockIdx.x) * nnz;
         for (int e = tid; e < nnz; e += kThreads)
-            msg[e] = 0.0 - dm_log(__builtin_fabs(src[e])); // lambda -> LLR: one logarithm per message
+            msg[e] = a.handover_llr ? src[e] : 0.0 - dm_log(__builtin_fabs(src[e])); // lambda -> LLR: one logarithm per message
+                                                                                        // (the fused form hands over LLRs)
     }
     else
     {

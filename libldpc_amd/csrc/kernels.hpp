@@ -96,6 +96,7 @@ struct DecodeArgs
     uint32_t *redo_iter;
     const uint32_t *redo_iter_in;
     double *ws_handover;
+    int handover_llr; // ws_handover holds the c2v messages as LLRs already (the fused form's hand-over), not as lambda
     uint64_t *phase_trace; // debug builds with -DLDPC_AMD_PHASE_TRACE only: [2048 frames of mid-launch][4 waves][8 values]
 };
 
@@ -140,9 +141,13 @@ struct DevFusedPlan
     const uint32_t *vn_desc;     // [kDecodeWaves][kFusedVnSlots][4]
     const uint32_t *vn_slot;
     const uint32_t *lane_tab;    // [kDecodeWaves][kFusedLaneRows][64]
+    const uint32_t *ho_map;      // [n_slots] (plan.hpp, FusedPlan::ho_map)
 };
 // first launch of sum-product with early termination (a.redo_list / a.redo_count set, a.early_term, no a.redo_count_in)
 int launch_decode_fused(const DecodeArgs &a, const DevFusedPlan &f, void *stream);
+// the same form WITHOUT early termination: separately divided outputs, hand-over to the LLR-domain form (a.redo_iter,
+// a.ws_handover as for the general kernel; the messages arrive there as LLRs: set handover_llr for the resuming launch)
+int launch_decode_fused_handover(const DecodeArgs &a, const DevFusedPlan &f, void *stream);
 // min-sum without early termination on the same plan (no redo lists)
 int launch_decode_fused_minsum(const DecodeArgs &a, const DevFusedPlan &f, void *stream);
 

@@ -72,7 +72,7 @@ __device__ __forceinline__ void track2(Track &t, double a, double b)
 // One call = one or two blocks (TWO: both full, 64 nodes) of one class <D, LEAF, FLIP>: M = D - LEAF message inputs per node
 // at p + k * stride, the leaf's channel ratio in rho*.  prev* (bit 31): the leaf's decision of the previous pass, which
 // joins the parity of the node; lb*: its new decision.  Returns the parity words (bit 31 counts) of the nodes, or-ed.
-template <int D, bool LEAF, unsigned FLIP, bool TWO, bool WANT_TOT>
+template <int D, bool LEAF, unsigned FLIP, bool TWO, bool WANT_TOT, bool SHARED = true>
 __device__ __forceinline__ uint32_t cnf_call(char *msg, uint32_t off0, uint32_t off1, uint32_t cnt0, int lane, double rho0, double rho1,
                                              uint32_t prev0, uint32_t prev1, uint32_t &lb0, uint32_t &lb1, Track &t, double &tot0,
                                              double &tot1)
@@ -106,9 +106,9 @@ __device__ __forceinline__ uint32_t cnf_call(char *msg, uint32_t off0, uint32_t 
         if constexpr (D == 2)
             h = dm_cnf2(v, FLIP);
         else if constexpr (D == 3)
-            h = dm_cnf3(v, FLIP, LEAF, &lb, WANT_TOT ? &tot : nullptr);
+            h = dm_cnf3(v, FLIP, LEAF, SHARED, &lb, WANT_TOT ? &tot : nullptr);
         else
-            h = dm_cnf4(v, FLIP, LEAF, &lb, WANT_TOT ? &tot : nullptr);
+            h = dm_cnf4(v, FLIP, LEAF, SHARED, &lb, WANT_TOT ? &tot : nullptr);
         t.pmax = max(t.pmax, h);
     };
     node(v0, lb0, tot0);
@@ -374,7 +374,7 @@ __device__ __forceinline__ bool stage_channel(const DecodeArgs &a, const DevFuse
 }
 
 // =======================================================================================================================
-template <bool WANT_LLR, int VNB, int CNL, bool EXCL>
+template <bool WANT_LLR, int VNB, int CNL, bool EXCL, bool HO = false>
 __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPlan &F)
 {
     extern __shared__ double lds[];
@@ -502,7 +502,7 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
                 if (q < deg)
                     *at(msg, (wide_idx[q >> 1] >> (16 * (q & 1))) & 0xFFFFu) = first_v2c[w];
         }
-        else
+        else if constexpr (!EXCL)
         {
             const uint32_t *idx = F.vn_slot + my_vdesc[4 * w + 1] + lane;
             for (int p = 0; p < deg; ++p)
@@ -534,18 +534,22 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
     uint32_t vn_bits = 0;   // bit w: decision of this lane's node in slot w
     [[maybe_unused]] double leaf_tot[2 * CNL];
     uint32_t I = 0;
-    for (;;)
-    {
-        // ---- loop pass I: check-node pass I, which also sees — in the sign bits of its inputs and the leaf bits — the
-        // syndrome of the decisions of variable-node pass I-1 (decoder.cpp:25-45, decoder.h:47-64) ----
-        uint32_t bad = 0, new_leaf_bits = 0;
+    uint32_t bad = 0, new_leaf_bits = 0, bits = 0;
+    [[maybe_unused]] int32_t ho_key = 0; // HO: running maximum of dm_handover_key over the variable nodes' totals
+    auto leaf_calls_now = my_leaf_calls;
+    auto vdesc_now = my_vdesc;
+    uint32_t prog = vn_prog;
+    auto refresh_tables = [&] {
         // (the tables are read again in every pass, through pointers the compiler cannot see through: hoisted out of the loop,
         // the descriptors and every condition derived from them sit in scalar registers for the whole decode — more than
         // there are, and the surplus is spilled to vector-register lanes, v_readlane by v_readlane)
-        auto leaf_calls_now = my_leaf_calls;
-        auto vdesc_now = my_vdesc;
-        uint32_t prog = vn_prog;
+        leaf_calls_now = my_leaf_calls;
+        vdesc_now = my_vdesc;
+        prog = vn_prog;
         asm volatile("" : "+s"(leaf_calls_now), "+s"(vdesc_now), "+s"(prog));
+    };
+    auto cn_pass = [&] {
+        bad = 0, new_leaf_bits = 0;
 #pragma unroll
         for (int c = 0; c < CNL; ++c)
         {
@@ -561,10 +565,10 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
 #define LDPC_LEAF_CLASS(D, NM)                                                                                                                 \
     case cls_key(D, 1, NM):                                                                                                                    \
         if (two)                                                                                                                               \
-            par = cnf_call<D, true, cls_flip(D, 1, NM), true, WANT_LLR>(msg, offs & 0xFFFFu, offs >> 16, cnt0, lane, leaf_rho[2 * c],          \
+            par = cnf_call<D, true, cls_flip(D, 1, NM), true, WANT_LLR, !HO>(msg, offs & 0xFFFFu, offs >> 16, cnt0, lane, leaf_rho[2 * c],          \
                                                                         leaf_rho[2 * c + 1], prev0, prev1, lb0, lb1, t, tot0, tot1);           \
         else if (lane < static_cast<int>(cnt0))                                                                                                \
-            par = cnf_call<D, true, cls_flip(D, 1, NM), false, WANT_LLR>(msg, offs & 0xFFFFu, 0, cnt0, lane, leaf_rho[2 * c],                  \
+            par = cnf_call<D, true, cls_flip(D, 1, NM), false, WANT_LLR, !HO>(msg, offs & 0xFFFFu, 0, cnt0, lane, leaf_rho[2 * c],                  \
                                                                          leaf_rho[2 * c + 1], prev0, prev1, lb0, lb1, t, tot0, tot1);          \
         break;
             switch (cls) // wave-uniform
@@ -597,10 +601,10 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
 #define LDPC_CLASS(D, NM)                                                                                                                      \
     case cls_key(D, 0, NM):                                                                                                                    \
         if (two)                                                                                                                               \
-            par = cnf_call<D, false, cls_flip(D, 0, NM), true, false>(msg, offs & 0xFFFFu, offs >> 16, cnt0, lane, 0.0, 0.0, 0u, 0u, lb0, lb1, \
+            par = cnf_call<D, false, cls_flip(D, 0, NM), true, false, !HO>(msg, offs & 0xFFFFu, offs >> 16, cnt0, lane, 0.0, 0.0, 0u, 0u, lb0, lb1, \
                                                                       t, tot0, tot1);                                                          \
         else if (lane < static_cast<int>(cnt0))                                                                                                \
-            par = cnf_call<D, false, cls_flip(D, 0, NM), false, false>(msg, offs & 0xFFFFu, 0, cnt0, lane, 0.0, 0.0, 0u, 0u, lb0, lb1, t,      \
+            par = cnf_call<D, false, cls_flip(D, 0, NM), false, false, !HO>(msg, offs & 0xFFFFu, 0, cnt0, lane, 0.0, 0.0, 0u, 0u, lb0, lb1, t,      \
                                                                        tot0, tot1);                                                            \
         break;
             switch (cls) // wave-uniform
@@ -622,6 +626,199 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
 #undef LDPC_CLASS
             bad |= par;
         }
+    };
+    auto commit_leaves = [&] {
+        leaf_bits = new_leaf_bits; // the leaves' decisions of pass I (decoder.cpp:58 for a node of degree 1)
+        if constexpr (WANT_LLR)
+        {
+#pragma unroll
+            for (int c = 0; c < 2 * CNL; ++c)
+                if (const uint32_t cwd = tab[(36 + c) * kWaveSize]; cwd != kFusedNone)
+                    out_llr[cwd & 0x3FFFFFFFu] = 0.0 - dm_log(leaf_tot[c]);
+        }
+    };
+    auto vn_pass = [&] {
+        // ---- variable-node pass I, APP and hard decision: decoder.cpp:48-64 ----
+        bits = 0;
+        auto note = [&](int w, uint32_t sg) { bits |= (sg >> 31) << w; };
+        auto note_total = [&](double total) { // HO: how far the node's total is from 1 (detmath.h, dm_handover_key)
+            if constexpr (HO)
+            {
+                const int32_t k = dm_handover_key(total);
+                ho_key = k > ho_key ? k : ho_key;
+            }
+        };
+        [[maybe_unused]] auto put_llr = [&](int w, double llr) {
+            if constexpr (WANT_LLR)
+                out_llr[tab[(24 + w) * kWaveSize] & 0x3FFFFFFFu] = llr;
+        };
+        auto one = [&](int w, uint32_t kind) {
+            const uint32_t d0 = vdesc_now[4 * w];
+            const int cnt = static_cast<int>(d0 & 0xFFFFu), deg = static_cast<int>(d0 >> 16);
+            if (lane >= cnt)
+                return;
+            uint32_t sg;
+            if (kind == kFusedVnPair || kind == kFusedVn2)
+            {
+                double tt;
+                vn2_one(msg, idx_at(w), val_at(w), t, sg, tt);
+                note_total(tt);
+                put_llr(w, dm_log(tt));
+            }
+            else
+            {
+                double prod = 1.0;
+                if (w == 0 && kind == kFusedVnWide)
+                    switch (deg) // wave-uniform
+                    {
+#define LDPC_VN(DV) \
+    case DV: prod = vn_wide<DV, EXCL>(msg, wide_idx, my_val[0], t, sg); break;
+                        LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8) LDPC_VN(9)
+                        LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15)
+#undef LDPC_VN
+                    default: sg = 0; break;
+                    }
+                else if constexpr (!EXCL) // (the small instantiation takes plans without such blocks: FusedPlan::wide_exclusive)
+                    prod = vn_table(msg, F.vn_slot + vdesc_now[4 * w + 1], lane, cnt, deg, val_at(w), t, sg);
+                else
+                    sg = 0;
+                note_total(prod);
+                put_llr(w, 0.0 - dm_log(prod));
+            }
+            note(w, sg);
+        };
+#pragma unroll
+        for (int w = 0; w < VNB; w += 2)
+        {
+            const uint32_t k01 = (prog >> (4 * w)) & 0xFFu; // (wave-uniform)
+            if (k01 == (kFusedVnPair | (kFusedVnPair << 4)))
+            {
+                uint32_t sga, sgb;
+                double ta, tb;
+                vn2_pair(msg, idx_at(w), idx_at(w + 1), val_at(w), val_at(w + 1), t, sga, sgb, ta, tb);
+                note(w, sga), note(w + 1, sgb);
+                note_total(ta), note_total(tb);
+                put_llr(w, dm_log(ta)), put_llr(w + 1, dm_log(tb));
+            }
+            else
+            {
+                if (k01 & 0xFu)
+                    one(w, k01 & 0xFu);
+                if (k01 >> 4)
+                    one(w + 1, k01 >> 4);
+            }
+        }
+        vn_bits = bits;
+    };
+    if constexpr (HO)
+    {
+        // Without early termination (detmath.h "Hand-over", separately divided check-node outputs): the checks of a pass come
+        // FIRST — on what the prologue or the variable-node pass before left behind, voted at the barrier that ends it — so a
+        // frame that has run its iterations makes no check-node pass too many, and the pass that hands a frame over can be
+        // the one that writes its c2v messages, as LLRs in the general plan's slot order, for the LLR-domain kernel
+        // (kernels.hip, decode_kernel<..., RATIO = false> resuming) to continue with.
+        auto post_vote = [&](uint32_t pass) {
+            const int wave_vote = ((__ballot(dm_box_escaped(t.hmax, t.hmin)) != 0) << 1) | ((__ballot(DM_HANDOVER_DUE(ho_key)) != 0) << 2);
+            if (lane == 0)
+                votes[pass & 1][wave] = wave_vote;
+        };
+        post_vote(0);
+        __syncthreads();
+        for (;;)
+        {
+            int any = 0;
+#pragma unroll
+            for (int w = 0; w < kDecodeWaves; ++w)
+                any |= votes[I & 1][w];
+            if (any & 2) // a value left the box: the LLR-domain form decodes the frame from scratch
+            {
+                if (tid == 0)
+                {
+                    const uint32_t pos = atomicAdd(a.redo_count, 1u);
+                    a.redo_list[pos] = static_cast<uint32_t>(frame);
+                    a.redo_iter[pos] = 0xFFFFFFFFu;
+                }
+                return;
+            }
+            if (I == a.iterations)
+                break;
+            refresh_tables();
+            if (any & 4) // a total of variable-node pass I-1 left the inner box: check-node pass I is the last one here
+            {
+                if (tid == 0)
+                {
+                    const uint32_t pos = atomicAdd(a.redo_count, 1u);
+                    a.redo_list[pos] = static_cast<uint32_t>(frame);
+                    a.redo_iter[pos] = I;
+                    misc[1] = static_cast<int>(pos);
+                }
+                __syncthreads();
+                double *dst = a.ws_handover + static_cast<uint64_t>(static_cast<uint32_t>(misc[1])) * P.nnz;
+                // every output of every check node as lambda, divided on its own, leaves included (dm_cnf*(flip 0, leaf 0,
+                // shared 0)); c2v = -log lambda.  Once per frame: rolled, no templates.
+                auto ho_call = [&](uint32_t offs, uint32_t cnts, uint32_t cls, int leaf_slot) {
+                    const int D = static_cast<int>(cls & 7u), leaf = static_cast<int>((cls >> 3) & 1u), M = D - leaf;
+                    for (int h = 0; h < 2; ++h)
+                    {
+                        const uint32_t off = h ? offs >> 16 : offs & 0xFFFFu, cnt = h ? cnts >> 16 : cnts & 0xFFFFu;
+                        if (static_cast<uint32_t>(lane) >= cnt)
+                            continue;
+                        double v[4] = {1.0, 1.0, 1.0, 1.0};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k < M)
+                                v[k] = __builtin_fabs(*at(msg, off + (k * cnt + lane) * 8u));
+                        const double rl = leaf ? leaf_rho[(2 * leaf_slot + h) & (2 * CNL - 1)] : 1.0;
+                        uint32_t lb = 0;
+                        if (D == 2)
+                            dm_cnf2(v, 0u);
+                        else if (D == 3)
+                        {
+                            if (leaf)
+                                v[2] = rl;
+                            dm_cnf3(v, 0u, 0, 0, &lb, nullptr);
+                        }
+                        else
+                        {
+                            if (leaf)
+                                v[3] = rl;
+                            dm_cnf4(v, 0u, 0, 0, &lb, nullptr);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k < M)
+                                dst[F.ho_map[off / 8u + k * cnt + lane]] = 0.0 - dm_log(v[k]);
+                        if (leaf)
+                            dst[tab[(40 + ((2 * leaf_slot + h) & 3)) * kWaveSize]] = 0.0 - dm_log(D == 3 ? v[2] : v[3]);
+                    }
+                };
+                for (int c = 0; c < CNL; ++c)
+                    if ((leaf_calls_now[4 * c + 1] & 0xFFFFu) != 0)
+                        ho_call(leaf_calls_now[4 * c], leaf_calls_now[4 * c + 1], leaf_calls_now[4 * c + 2], c);
+                for (int c = 0; c < F.calls_stride; ++c)
+                {
+                    if ((my_calls[4 * c + 1] & 0xFFFFu) == 0)
+                        break;
+                    ho_call(my_calls[4 * c], my_calls[4 * c + 1], my_calls[4 * c + 2], 0);
+                }
+                return;
+            }
+            cn_pass();
+            commit_leaves();
+            __syncthreads();
+            vn_pass();
+            post_vote(I + 1);
+            __syncthreads();
+            ++I;
+        }
+    }
+    else
+    for (;;)
+    {
+        // ---- loop pass I: check-node pass I, which also sees — in the sign bits of its inputs and the leaf bits — the
+        // syndrome of the decisions of variable-node pass I-1 (decoder.cpp:25-45, decoder.h:47-64) ----
+        refresh_tables();
+        cn_pass();
         const int ph = I & 1;
         const bool esc = dm_box_escaped(t.hmax, t.hmin) || t.pmax >= DM_FUSED_P_HI;
         const int wave_vote = (__ballot((bad & 0x80000000u) != 0) != 0) | ((__ballot(esc) != 0) << 1);
@@ -648,74 +845,9 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
         }
         if (I == a.iterations)
             break;
-        leaf_bits = new_leaf_bits; // the leaves' decisions of pass I (decoder.cpp:58 for a node of degree 1)
-        if constexpr (WANT_LLR)
-        {
-#pragma unroll
-            for (int c = 0; c < 2 * CNL; ++c)
-                if (const uint32_t cwd = tab[(36 + c) * kWaveSize]; cwd != kFusedNone)
-                    out_llr[cwd & 0x3FFFFFFFu] = 0.0 - dm_log(leaf_tot[c]);
-        }
+        commit_leaves();
 
-        // ---- variable-node pass I, APP and hard decision: decoder.cpp:48-64 ----
-        uint32_t bits = 0;
-        auto note = [&](int w, uint32_t sg) { bits |= (sg >> 31) << w; };
-        [[maybe_unused]] auto put_llr = [&](int w, double llr) {
-            if constexpr (WANT_LLR)
-                out_llr[tab[(24 + w) * kWaveSize] & 0x3FFFFFFFu] = llr;
-        };
-        auto one = [&](int w, uint32_t kind) {
-            const uint32_t d0 = vdesc_now[4 * w];
-            const int cnt = static_cast<int>(d0 & 0xFFFFu), deg = static_cast<int>(d0 >> 16);
-            if (lane >= cnt)
-                return;
-            uint32_t sg;
-            if (kind == kFusedVnPair || kind == kFusedVn2)
-            {
-                double tt;
-                vn2_one(msg, idx_at(w), val_at(w), t, sg, tt);
-                put_llr(w, dm_log(tt));
-            }
-            else
-            {
-                double prod = 1.0;
-                if (w == 0 && kind == kFusedVnWide)
-                    switch (deg) // wave-uniform
-                    {
-#define LDPC_VN(DV) \
-    case DV: prod = vn_wide<DV, EXCL>(msg, wide_idx, my_val[0], t, sg); break;
-                        LDPC_VN(3) LDPC_VN(4) LDPC_VN(5) LDPC_VN(6) LDPC_VN(7) LDPC_VN(8) LDPC_VN(9)
-                        LDPC_VN(10) LDPC_VN(11) LDPC_VN(12) LDPC_VN(13) LDPC_VN(14) LDPC_VN(15)
-#undef LDPC_VN
-                    default: sg = 0; break;
-                    }
-                else
-                    prod = vn_table(msg, F.vn_slot + vdesc_now[4 * w + 1], lane, cnt, deg, val_at(w), t, sg);
-                put_llr(w, 0.0 - dm_log(prod));
-            }
-            note(w, sg);
-        };
-#pragma unroll
-        for (int w = 0; w < VNB; w += 2)
-        {
-            const uint32_t k01 = (prog >> (4 * w)) & 0xFFu; // (wave-uniform)
-            if (k01 == (kFusedVnPair | (kFusedVnPair << 4)))
-            {
-                uint32_t sga, sgb;
-                double ta, tb;
-                vn2_pair(msg, idx_at(w), idx_at(w + 1), val_at(w), val_at(w + 1), t, sga, sgb, ta, tb);
-                note(w, sga), note(w + 1, sgb);
-                put_llr(w, dm_log(ta)), put_llr(w + 1, dm_log(tb));
-            }
-            else
-            {
-                if (k01 & 0xFu)
-                    one(w, k01 & 0xFu);
-                if (k01 >> 4)
-                    one(w + 1, k01 >> 4);
-            }
-        }
-        vn_bits = bits;
+        vn_pass();
         __syncthreads();
         ++I;
     }
@@ -1134,6 +1266,20 @@ decode_fused_small(const DecodeArgs a, const DevFusedPlan f)
 }
 
 template <bool WANT_LLR, int VNB, int CNL>
+__global__ __launch_bounds__(kThreads) void decode_fused_ho_kernel(const DecodeArgs a, const DevFusedPlan f)
+{
+    fused_body<WANT_LLR, VNB, CNL, false, true>(a, f);
+}
+
+// (no LLR output, four blocks, one leaf call: the n = 1024 code without early termination; separately divided outputs keep
+// more values live than the shared reciprocals do: five waves per SIMD — at six the compiler spills 104 bytes per lane)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void
+decode_fused_ho_small(const DecodeArgs a, const DevFusedPlan f)
+{
+    fused_body<false, 4, 1, true, true>(a, f);
+}
+
+template <bool WANT_LLR, int VNB, int CNL>
 __global__ __launch_bounds__(kThreads) void decode_fused_kernel(const DecodeArgs a, const DevFusedPlan f)
 {
     fused_body<WANT_LLR, VNB, CNL, false>(a, f);
@@ -1155,6 +1301,27 @@ int launch_decode_fused(const DecodeArgs &a, const DevFusedPlan &f, void *stream
         k = (want_llr || !f.wide_exclusive) ? (want_llr ? decode_fused_kernel<true, 4, 1> : decode_fused_kernel<false, 4, 1>) : decode_fused_small;
     else
         k = want_llr ? decode_fused_kernel<true, kFusedVnSlots, kFusedLeafCalls> : decode_fused_kernel<false, kFusedVnSlots, kFusedLeafCalls>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(f.lds_bytes));
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(a.n_frames)), dim3(kThreads), f.lds_bytes, static_cast<hipStream_t>(stream), a, f);
+    return hipGetLastError();
+}
+
+int launch_decode_fused_handover(const DecodeArgs &a, const DevFusedPlan &f, void *stream)
+{
+    if (a.n_frames == 0)
+        return hipSuccess;
+    if (!a.redo_list || !a.redo_count || !a.redo_iter || !a.ws_handover || a.redo_count_in || a.early_term || a.iterations == 0)
+        return hipErrorInvalidValue;
+    if (f.vnb > kFusedVnSlots || f.cnl > kFusedLeafCalls)
+        return hipErrorInvalidValue;
+    const bool want_llr = a.llr_out != nullptr;
+    void (*k)(const DecodeArgs, const DevFusedPlan) = nullptr;
+    if (f.vnb <= 4 && f.cnl <= 1)
+        k = (want_llr || !f.wide_exclusive) ? (want_llr ? decode_fused_ho_kernel<true, 4, 1> : decode_fused_ho_kernel<false, 4, 1>) : decode_fused_ho_small;
+    else
+        k = want_llr ? decode_fused_ho_kernel<true, kFusedVnSlots, kFusedLeafCalls> : decode_fused_ho_kernel<false, kFusedVnSlots, kFusedLeafCalls>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(f.lds_bytes));
     if (e != hipSuccess)
         return e;

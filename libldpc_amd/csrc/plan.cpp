@@ -535,6 +535,10 @@ FusedPlan build_fused_plan(const LdpcCode &code, const Plan &plan)
     f.n_slots = static_cast<int>(slot);
     if (f.n_slots > DM_FUSED_MAX_SLOTS)
         return f;
+    f.ho_map.assign(static_cast<size_t>(f.n_slots), 0);
+    for (int e = 0; e < plan.nnz; ++e)
+        if (f.edge_slot[e] != kNoSlot)
+            f.ho_map[f.edge_slot[e]] = plan.edge_slot[e];
 
     // ---- calls: consecutive full blocks of a class two at a time ----
     struct Call
@@ -683,6 +687,8 @@ FusedPlan build_fused_plan(const LdpcCode &code, const Plan &plan)
             std::fill(tab + r * kWaveSize, tab + (r + 1) * kWaveSize, kFusedNone);
         for (int r = 36; r < 40; ++r)
             std::fill(tab + r * kWaveSize, tab + (r + 1) * kWaveSize, kFusedNone);
+        for (int r = 40; r < 44; ++r)
+            std::fill(tab + r * kWaveSize, tab + (r + 1) * kWaveSize, 0u);
         // widest first; the degree-2 blocks from an even slot on
         std::vector<int> &mine = w_vn[w];
         std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return vblocks[a].degree > vblocks[b].degree; });
@@ -737,6 +743,7 @@ FusedPlan build_fused_plan(const LdpcCode &code, const Plan &plan)
                     const int col = H.rcol[H.rptr[b.rows[l].row] + b.rows[l].order[d - 1]]; // the leaf: the last input
                     tab[(32 + 2 * c + h) * kWaveSize + l] = col_entry[col] * 16u;
                     tab[(36 + 2 * c + h) * kWaveSize + l] = col_word[col];
+                    tab[(40 + 2 * c + h) * kWaveSize + l] = plan.edge_slot[H.redge[H.rptr[b.rows[l].row] + b.rows[l].order[d - 1]]];
                 }
             }
     }
@@ -744,8 +751,13 @@ FusedPlan build_fused_plan(const LdpcCode &code, const Plan &plan)
         f.vn_slot.push_back(0);
     f.wide_exclusive = true;
     for (int w = 0; w < W; ++w)
+    {
         if ((f.vn_prog[w] & 0xFu) == kFusedVnWide && (f.vn_prog[w] >> 4) != 0)
             f.wide_exclusive = false;
+        for (int sw = 0; sw < kFusedVnSlots; ++sw) // (and no block that goes through the slot table)
+            if (((f.vn_prog[w] >> (4 * sw)) & 0xFu) == kFusedVnTable)
+                f.wide_exclusive = false;
+    }
     f.ok = true;
     return f;
 }

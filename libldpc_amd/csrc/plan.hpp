@@ -196,7 +196,7 @@ LayerPlan build_layer_plan(const LdpcCode &code, const Plan &plan);
 //   slot of (block, lane, k-th message input) = off + k * count + lane; all offsets below are BYTE offsets (< 2^16).
 constexpr int kFusedVnSlots = 8;    // variable-node blocks per wave (general instantiation; the small one takes 4)
 constexpr int kFusedLeafCalls = 2;  // calls with leaves per wave (general instantiation; the small one takes 1)
-constexpr int kFusedLaneRows = 40;  // rows of the lane table
+constexpr int kFusedLaneRows = 44;  // rows of the lane table
 struct FusedCall
 {
     uint32_t offs; // block 0 | block 1 << 16
@@ -210,7 +210,9 @@ struct FusedPlan
     int n_slots = 0;     // message slots
     int vnb = 0, cnl = 0; // largest number of variable-node blocks / of leaf calls any wave holds
     bool has_shortened = false;
-    bool wide_exclusive = false; // a wave that serves a block through register-held offsets (slot 0, degree 3..15) serves no other
+    // a wave that serves a block through register-held offsets (slot 0, degree 3..15) serves no other, and no block goes
+    // through the slot table: what the small instantiation of the kernel is compiled for
+    bool wide_exclusive = false;
     std::vector<FusedCall> leaf_calls; // [kDecodeWaves][kFusedLeafCalls]
     std::vector<FusedCall> calls;      // [kDecodeWaves][calls_stride], each row ends in a zero entry
     int calls_stride = 0;
@@ -229,8 +231,11 @@ struct FusedPlan
     //   rows 24..31  slot w: the node's column | kFusedCounted (its bit is one the error count visits); kFusedNone = no node
     //   rows 32..35  leaf call c, block h (row 32 + 2c + h): stage entry of the leaf's channel value
     //   rows 36..39  ... and the leaf's column | flags
+    //   rows 40..43  ... and the message slot of the leaf's edge in the GENERAL plan (Plan::edge_slot: the hand-over)
     std::vector<uint32_t> lane_tab;
     std::vector<uint32_t> edge_slot;   // file-order edge -> slot, kNoSlot for an edge that ends in a leaf (tests)
+    std::vector<uint32_t> ho_map;      // [n_slots] slot -> the same edge's slot in the general plan (the hand-over hands the
+                                       // frame's c2v messages to the LLR-domain kernel in that plan's order)
 };
 constexpr uint32_t kFusedCounted = 0x80000000u, kFusedNone = 0xFFFFFFFFu;
 enum : uint32_t { kFusedVnNone = 0, kFusedVnPair = 1 /* degree 2, 64 nodes */, kFusedVn2 = 2 /* degree 2 */, kFusedVnWide = 3 /* slot 0, degree 3..15 */, kFusedVnTable = 4 };

@@ -813,6 +813,42 @@ static int fused_applies(const orc_code *c)
     return handover_applies(c) && dm_fused_applies(H->rows, H->cols, H->rptr, H->rnode, H->cptr);
 }
 
+/* one check-node pass of the fused form; handover: the pass that ends the ratio form (every output as lambda, separately
+   divided, leaf included) and leaves c2v[] as LLRs for the LLR-domain form to continue with */
+static int fused_cn_pass(dec_t *d, const double *rho, int shared, int handover, uint8_t *lbit, double *ltot)
+{
+    const spm *H = &d->code->H;
+    int escaped = 0;
+    for (int i = 0; i < H->rows; ++i)
+    {
+        const int cw = H->rptr[i + 1] - H->rptr[i];
+        const int *cn = H->redge + H->rptr[i], *cols = H->rnode + H->rptr[i];
+        int order[4], leaf;
+        unsigned flip;
+        double v[4], tot = 1.0;
+        uint32_t lb = 0, h;
+        (void)rho;
+        if (!dm_fused_row_order(cw, cols, H->cptr, order, &flip, &leaf))
+            return 1; /* cannot happen: fused_applies */
+        for (int k = 0; k < cw; ++k)
+            v[k] = d->v2c[cn[order[k]]];
+        if (handover)
+            flip = 0, leaf = 0;
+        if (cw == 2)
+            h = dm_cnf2(v, flip);
+        else if (cw == 3)
+            h = dm_cnf3(v, flip, leaf, shared, &lb, &tot);
+        else
+            h = dm_cnf4(v, flip, leaf, shared, &lb, &tot);
+        escaped |= shared && h >= DM_FUSED_P_HI;
+        for (int k = 0; k < cw - leaf; ++k)
+            d->c2v[cn[order[k]]] = handover ? 0.0 - dm_log(v[k]) : v[k];
+        if (leaf)
+            lbit[cols[order[cw - 1]]] = (uint8_t)lb, ltot[cols[order[cw - 1]]] = tot;
+    }
+    return escaped;
+}
+
 static int dec_decode_fused(dec_t *d)
 {
     const spm *H = &d->code->H;
@@ -820,6 +856,7 @@ static int dec_decode_fused(dec_t *d)
     double *lam = malloc(8 * (size_t)nc), *rho = malloc(8 * (size_t)nc), *ltot = malloc(8 * (size_t)nc);
     uint8_t *lbit = malloc((size_t)nc);
     int escaped = 0, ret = -1;
+    int32_t ho_key = 0;
     for (int i = 0; i < nc; ++i)
     {
         double L = d->llr_in[i];
@@ -829,47 +866,44 @@ static int dec_decode_fused(dec_t *d)
         for (int p = H->cptr[i]; p < H->cptr[i + 1]; ++p)
             d->v2c[H->cedge[p]] = rho[i];
     }
+    /* with early termination: shared reciprocals, and loop pass I = check-node pass I, then the checks on what variable-node
+       pass I-1 left behind, then variable-node pass I (dec_decode_ratio).  Without: separately divided outputs, the checks
+       come first, and a frame whose totals near the edge of the box is handed to the LLR-domain form (detmath.h "Hand-over") */
+    const int shared = d->early_term;
     unsigned I = 0;
     for (;;)
     {
-        for (int i = 0; i < H->rows; ++i)
+        if (!d->early_term)
         {
-            const int cw = H->rptr[i + 1] - H->rptr[i];
-            const int *cn = H->redge + H->rptr[i], *cols = H->rnode + H->rptr[i];
-            int order[4], leaf;
-            unsigned flip;
-            double v[4], tot = 1.0;
-            uint32_t lb = 0, h;
-            if (!dm_fused_row_order(cw, cols, H->cptr, order, &flip, &leaf))
+            if (escaped)
+                break;
+            if (I == d->iterations)
             {
-                escaped = 1; /* cannot happen: fused_applies */
+                ret = (int)I;
                 break;
             }
-            for (int k = 0; k < cw; ++k)
-                v[k] = d->v2c[cn[order[k]]];
-            if (cw == 2)
-                h = dm_cnf2(v, flip);
-            else if (cw == 3)
-                h = dm_cnf3(v, flip, leaf, &lb, &tot);
-            else
-                h = dm_cnf4(v, flip, leaf, &lb, &tot);
-            escaped |= h >= DM_FUSED_P_HI;
-            for (int k = 0; k < cw - leaf; ++k)
-                d->c2v[cn[order[k]]] = v[k];
-            if (leaf)
-                lbit[cols[order[cw - 1]]] = (uint8_t)lb, ltot[cols[order[cw - 1]]] = tot;
+            if (DM_HANDOVER_DUE(ho_key))
+            {
+                fused_cn_pass(d, rho, 0, 1, lbit, ltot);
+                free(lam), free(rho), free(ltot), free(lbit);
+                return dec_decode_llr_from(d, I, 1);
+            }
         }
-        if (escaped)
-            break;
-        if (I > 0 && d->early_term && is_codeword(d))
+        escaped |= fused_cn_pass(d, rho, shared, 0, lbit, ltot);
+        if (d->early_term)
         {
-            ret = (int)I - 1;
-            break;
-        }
-        if (I == d->iterations)
-        {
-            ret = (int)I;
-            break;
+            if (escaped)
+                break;
+            if (I > 0 && is_codeword(d))
+            {
+                ret = (int)I - 1;
+                break;
+            }
+            if (I == d->iterations)
+            {
+                ret = (int)I;
+                break;
+            }
         }
         for (int i = 0; i < nc; ++i)
         {
@@ -884,6 +918,8 @@ static int dec_decode_fused(dec_t *d)
                 const int e0 = H->cedge[H->cptr[i]], e1 = H->cedge[H->cptr[i] + 1];
                 const double c0 = d->c2v[e0], c1 = d->c2v[e1];
                 const double o0 = rho[i] * c1, o1 = rho[i] * c0, tot = o0 * c0;
+                const int32_t hk = dm_handover_key(tot);
+                ho_key = hk > ho_key ? hk : ho_key;
                 d->co[i] = (uint8_t)(tot <= 1.0);
                 d->llr_out[i] = dm_log(tot);
                 escaped |= dm_ratio_out_of_range(o0) | dm_ratio_out_of_range(o1);
@@ -898,6 +934,8 @@ static int dec_decode_fused(dec_t *d)
                     if (deg > 3 && k % 3 == 2)
                         escaped |= dm_ratio_out_of_range(prod);
                 }
+                const int32_t hk = dm_handover_key(prod);
+                ho_key = hk > ho_key ? hk : ho_key;
                 d->co[i] = (uint8_t)(prod >= 1.0);
                 d->llr_out[i] = 0.0 - dm_log(prod);
                 const double tot = 1.0 / prod;
@@ -941,7 +979,7 @@ static int dec_decode(dec_t *d)
         /* three stages, as the kernels' three launches: shared-reciprocal check nodes; if a value (or a denominator product)
            leaves its range, again from scratch with separately divided outputs; if the box is left there too, the LLR domain */
         /* (first stage: the fused form where the code's structure admits it, fused_rule.h) */
-        int it = (d->early_term && fused_applies(d->code)) ? dec_decode_fused(d) : dec_decode_ratio(d, 1);
+        int it = fused_applies(d->code) ? dec_decode_fused(d) : dec_decode_ratio(d, 1);
         if (it < 0 && d->early_term && handover_applies(d->code))
         {
             ++g_ratio_second;

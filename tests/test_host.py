@@ -254,6 +254,16 @@ def test_headline_kernel_register_budget():
     assert len(key) == 1, key
     r = fused[key[0]]
     assert r["VGPRs"] <= 80 and r["ScratchSize [bytes/lane]"] == 0 and r["Occupancy [waves/SIMD]"] >= 6, r
+    # the same form without early termination (hand-over, separately divided outputs): five frames per CU, no scratch;
+    # min-sum on the fused plan (config 3): six
+    r = fused[[k for k in fused if "decode_fused_ho_small" in k][0]]
+    assert r["VGPRs"] <= 96 and r["ScratchSize [bytes/lane]"] == 0 and r["Occupancy [waves/SIMD]"] >= 5, r
+    r = fused[[k for k in fused if "decode_fused_ms_kernelILb0ELi4ELi1E" in k][0]]
+    assert r["VGPRs"] <= 80 and r["ScratchSize [bytes/lane]"] == 0, r
+    # the register-resident kernel of the n = 8192 code with early termination (config 4): no scratch either
+    reg2 = build.kernel_resources("kernels_reg2u.hip")
+    r = reg2[[k for k in reg2 if "decode_reg2_kernelILb0ELb0ELi1024ELi4ELi6ELi4ELi4ELb1ELb0ELb1ELb1E" in k][0]]
+    assert r["VGPRs"] <= 128 and r["ScratchSize [bytes/lane]"] == 0, r
     # decode_kernel_w5<MINSUM=false, WANT_LLR=false, LDS_RESIDENT=true, MAXD=4, LLR_MODE=kLlrRegs, RATIO=true>
     key = [k for k in res if "decode_kernel_w5ILb0ELb0ELb1ELi4ELi2ELb1E" in k]
     assert len(key) == 1, key

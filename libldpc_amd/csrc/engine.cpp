@@ -188,7 +188,7 @@ MtDevice::MtDevice()
     {
         const long v = std::strtol(e, nullptr, 10);
         if (v >= 1 && v <= (1 << 20))
-            chunk_blocks_ = static_cast<uint32_t>(v);
+            chunk_blocks_ = static_cast<uint32_t>(v), chunk_blocks_from_env_ = true;
     }
 }
 
@@ -478,8 +478,10 @@ Engine::Engine(const std::string &pc_file, const std::string &gen_file, int devi
             reg2_plan_ = build_reg2_plan(*code_, plan_, 1024, 4, 6, 4, 4);
         // a register-resident decode workgroup owns its CU: keep the noise generator of the next batch, which runs
         // beside it, on a quarter of the CUs (config 4: 4.89 -> 4.62 ms per step)
+        // ... and in chunks of 2240 blocks: half as many jump-ahead tasks per batch as the LDS-resident decoders' 1120 — here
+        // every task holds a CU that a frame could have, and the generator's longer chain still ends before the 4.6 ms launch
         if (reg_plan_.ok)
-            noise_.set_pack(4), noise_.st.set_jump_pack(3);
+            noise_.set_pack(4), noise_.st.set_jump_pack(3), noise_.st.set_default_chunk_blocks(2240);
     }
 }
 

@@ -88,6 +88,13 @@ class MtDevice
     void reset(uint64_t seed); // chunk states depend on the seed only: kept when it does not change
     uint64_t seed() const { return seed_; }
     uint32_t chunk_blocks() const { return chunk_blocks_; }
+    // before the first use of the stream only (the engine picks the chunk size by the decoder's residency; LDPC_AMD_CHUNK_BLOCKS
+    // overrides either choice)
+    void set_default_chunk_blocks(uint32_t blocks)
+    {
+        if (!chunk_blocks_from_env_)
+            chunk_blocks_ = blocks;
+    }
     uint64_t chunk_words() const { return static_cast<uint64_t>(kMtWords) * chunk_blocks_; }
     uint64_t chunk_trials() const { return chunk_words() / 2; }
     // consecutive chunks [c_lo, c_hi): their start states in the ring; returns the ring row of c_lo
@@ -113,6 +120,7 @@ class MtDevice
     uint64_t seed_ = 0;
     bool seeded_ = false;
     uint32_t chunk_blocks_;
+    bool chunk_blocks_from_env_ = false;
     StateRing ring_;
     StridedTable strided_;
     DeviceBuffer ring_buf_, strided_buf_;

@@ -18,7 +18,7 @@ line = json.loads([l for l in open(f"{out}/x{x}.log") if l.startswith("{")][-1])
 f = glob.glob(f"{out}/x{x}/**/*counter_collection.csv", recursive=True)[0]
 per = {}
 for r in csv.DictReader(open(f)):
-    if "decode_kernel_w5" in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU":
+    if ("decode_fused_small" in r["Kernel_Name"] or "decode_kernel_w5" in r["Kernel_Name"]) and r["Counter_Name"] == "SQ_INSTS_VALU":
         per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
 launches = sorted(per.items(), key=lambda kv: int(kv[0]))[-line["steps"]:]
 valu = sum(v for _, v in launches) * 64

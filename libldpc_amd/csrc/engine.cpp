@@ -1024,6 +1024,74 @@ const uint8_t *Engine::encode_frames(uint64_t n, bool want_codewords, void *stre
     return e.codeword;
 }
 
+const uint8_t *Engine::encode_frames_sharded(Comm &comm, uint64_t before, uint64_t n, uint64_t step_frames, void *stream)
+{
+    if (!code_->has_G() || step_frames == 0)
+        return nullptr;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nc = plan_.nc;
+    const uint64_t kc = static_cast<uint64_t>(code_->kc());
+    if (code_->kc() <= 0 || code_->G.rows > code_->kc())
+        throw std::runtime_error("generator matrix does not match the code (rows > nc - mc)");
+    const int words = static_cast<int>((kc + 63) / 64);
+    if (static_cast<size_t>(words) * 8 > Comm::kMaxBytes)
+        throw std::runtime_error("sharded encoding: more than 2048 information bits per frame do not fit the exchange");
+    uint8_t *prev = static_cast<uint8_t *>(cw_run_.reserve(nc));
+    if (!cw_run_valid_)
+    {
+        check(hipMemsetAsync(prev, 0, nc, s), "codeword reset");
+        cw_run_valid_ = true;
+    }
+    check(hipMemcpyAsync(cw_before_.reserve(nc), prev, nc, hipMemcpyDeviceToDevice, s), "codeword snapshot");
+    last_enc_n_ = n;
+    // this rank's frames: info words and their running XOR (the last entry is the XOR over the rank's range)
+    uint64_t *base = static_cast<uint64_t *>(enc_base_.reserve(8 * 2 * static_cast<size_t>(words)));
+    EncodeArgs e{};
+    e.nc = static_cast<int>(nc), e.kc = static_cast<int>(kc), e.words = words;
+    e.g_col_ptr = g_col_ptr_, e.g_col_row = g_col_row_, e.g_cols = code_->G.cols;
+    e.cw_prev = prev;
+    e.cw_last = static_cast<uint8_t *>(cw_next_.reserve(nc));
+    std::vector<uint64_t> mine(words, 0), all(static_cast<size_t>(words) * comm.world());
+    if (n)
+    {
+        e.info_raw = info_.generate(info_pos_ + before * kc, n * kc, stream);
+        e.prefix = static_cast<uint64_t *>(enc_prefix_.reserve(8 * n * words));
+        e.n_frames = n;
+        check(launch_encode_prefix(e, s), "encode (info words)");
+        check(hipMemcpyAsync(mine.data(), e.prefix + (n - 1) * words, 8 * static_cast<size_t>(words), hipMemcpyDeviceToHost, s), "info sum");
+        check(hipStreamSynchronize(s), "sync");
+    }
+    // ONE exchange: every rank's sum; the ranks before this one give the word every prefix of this rank starts from, all of
+    // them together the codeword after the step (the codeword accumulates linearly: channel.cpp:44-60)
+    const auto t0 = std::chrono::steady_clock::now();
+    comm.all_gather(mine.data(), all.data(), 8 * static_cast<size_t>(words));
+    host_ms_[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<uint64_t> host(2 * static_cast<size_t>(words), 0); // [0, words): ranks before this one; [words, 2 words): all
+    for (int q = 0; q < comm.world(); ++q)
+        for (int w = 0; w < words; ++w)
+        {
+            if (q < comm.rank())
+                host[w] ^= all[static_cast<size_t>(q) * words + w];
+            host[words + w] ^= all[static_cast<size_t>(q) * words + w];
+        }
+    check(hipMemcpyAsync(base, host.data(), 8 * host.size(), hipMemcpyHostToDevice, s), "info sums");
+    check(hipStreamSynchronize(s), "sync"); // (host is a local: the copy must have read it)
+    const uint8_t *cw = nullptr;
+    if (n)
+    {
+        e.base = base;
+        e.codeword = static_cast<uint8_t *>(cw_frames_.reserve(n * nc));
+        check(launch_encode_codewords(e, s, false), "encode (codewords)");
+        cw = e.codeword;
+    }
+    // the codeword after the step, on every rank: cw_prev ^ (sum over all ranks) G — one pseudo-frame whose prefix is that sum
+    e.prefix = base + words, e.base = nullptr, e.n_frames = 1, e.codeword = nullptr;
+    check(launch_encode_codewords(e, s, true), "encode (codeword carry)");
+    check(hipMemcpyAsync(prev, e.cw_last, nc, hipMemcpyDeviceToDevice, s), "codeword carry");
+    info_pos_ += step_frames * kc;
+    return cw;
+}
+
 void Engine::decode_llr(const DecParams &p, uint64_t n, const double *llr_in, const BatchOut &out, void *stream)
 {
     if (n == 0)
@@ -1597,24 +1665,12 @@ Engine::ShardStep Engine::stream_decode_sharded(Comm &comm, const DecParams &p, 
         st.n = base + (static_cast<uint64_t>(r) < extra ? 1 : 0);
         st.first = st.step_first + base * r + std::min<uint64_t>(r, extra);
     }
-    // encoder: every rank walks the whole step's info words (kc draws per frame, a tenth of the noise stream's) so
-    // that all of them hold the same accumulated codeword afterwards; codewords are formed for the own frames only
+    // encoder: a rank draws the info words of its own frames only; one all-gather of the ranks' info-word sums (ceil(kc / 64)
+    // words) gives each the word its prefixes start from and all of them the codeword accumulated over the step
     const uint8_t *cw = nullptr;
     if (code_->has_G())
     {
-        for (uint64_t left = st.first - st.step_first; left;)
-        {
-            const uint64_t n = std::min<uint64_t>(left, 1u << 17);
-            encode_frames(n, false, stream);
-            left -= n;
-        }
-        cw = encode_frames(st.n, true, stream);
-        for (uint64_t left = st.step_first + st.step_frames - (st.first + st.n); left;)
-        {
-            const uint64_t n = std::min<uint64_t>(left, 1u << 17);
-            encode_frames(n, false, stream);
-            left -= n;
-        }
+        cw = encode_frames_sharded(comm, st.first - st.step_first, st.n, st.step_frames, stream);
         last_enc_n_ = 0;
     }
     if (st.n)

@@ -264,6 +264,10 @@ class Engine
     // advance the encoder by n frames; returns the per-frame codewords [n][nc] (nullptr when no G is
     // loaded, or when want_codewords is false)
     const uint8_t *encode_frames(uint64_t n, bool want_codewords, void *stream);
+    // the encoder's part of a sharded step of step_frames frames of which this rank decodes [before, before + n): the rank
+    // draws the info words of ITS frames only, the ranks exchange the XOR of theirs (one all-gather of ceil(kc / 64) words),
+    // and every rank ends with the codeword accumulated over the whole step.  Returns this rank's codewords [n][nc].
+    const uint8_t *encode_frames_sharded(Comm &comm, uint64_t before, uint64_t n, uint64_t step_frames, void *stream);
 
     std::unique_ptr<LdpcCode> code_;
     Plan plan_;
@@ -304,6 +308,7 @@ class Engine
     void *ev_pairs_ready_[2] = {nullptr, nullptr}, *ev_pairs_free_[2] = {nullptr, nullptr};
     bool pairs_in_use_[2] = {false, false};
     int pp_ = 0;
+    DeviceBuffer enc_base_; // sharded encoding: the other ranks' info-word sums (two rows of `words`)
     DeviceBuffer stage_in_, stage_iters_, stage_be_, stage_hard_, stage_llr_out_, stage_llr_in_, stage_cw_;
     DeviceBuffer ws_msg_, ws_llr_, ws_hb_, ws_scr_;
     PinnedBuffer pin_in_, pin_out_;

@@ -2036,7 +2036,7 @@ __global__ __launch_bounds__(256) void encode_cw_kernel(const EncodeArgs a, uint
     extern __shared__ uint64_t pw[];
     const uint64_t f = first_frame + blockIdx.x;
     for (int w = threadIdx.x; w < a.words; w += 256)
-        pw[w] = a.prefix[f * a.words + w];
+        pw[w] = a.prefix[f * a.words + w] ^ (a.base ? a.base[w] : 0ull);
     __syncthreads();
     const bool last = f + 1 == a.n_frames;
     uint8_t *out = a.codeword ? a.codeword + f * a.nc : nullptr;
@@ -2261,6 +2261,30 @@ int launch_bec(const BecArgs &a, void *stream)
         return e;
     hipLaunchKernelGGL(bec_kernel, dim3(static_cast<unsigned>(a.n_frames)), dim3(kThreads), lds,
                        static_cast<hipStream_t>(stream), a);
+    return hipGetLastError();
+}
+
+int launch_encode_prefix(const EncodeArgs &a, void *stream)
+{
+    if (a.n_frames == 0)
+        return hipSuccess;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t items = a.n_frames * static_cast<uint64_t>(a.words);
+    hipLaunchKernelGGL(encode_info_kernel, dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(encode_prefix_kernel, dim3(a.words), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+int launch_encode_codewords(const EncodeArgs &a, void *stream, bool only_last)
+{
+    if (a.n_frames == 0)
+        return hipSuccess;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t lds = sizeof(uint64_t) * a.words;
+    if (!only_last && a.codeword)
+        hipLaunchKernelGGL(encode_cw_kernel, dim3(static_cast<unsigned>(a.n_frames)), dim3(256), lds, s, a, uint64_t(0));
+    else
+        hipLaunchKernelGGL(encode_cw_kernel, dim3(1), dim3(256), lds, s, a, a.n_frames - 1);
     return hipGetLastError();
 }
 

@@ -280,8 +280,15 @@ struct EncodeArgs
     uint8_t *codeword;         // [n_frames][nc], may be nullptr (skip: only cw_last is wanted)
     uint8_t *cw_last;          // [nc] codeword after the batch
     uint64_t n_frames;
+    // sharded encoding: XOR of the info words of the step's frames before this rank's (0 for a whole stream): joins every
+    // prefix of the batch (the codeword accumulates linearly over the frames: channel.cpp:44-60, sparse.h:163-172)
+    const uint64_t *base;      // [words] device, or nullptr
 };
 int launch_encode(const EncodeArgs &a, void *stream);
+// the two halves of launch_encode by themselves (sharded encoding): info words + their running XOR over the batch; the
+// codewords of the batch (only_last: just cw_last, from the batch's last prefix)
+int launch_encode_prefix(const EncodeArgs &a, void *stream);
+int launch_encode_codewords(const EncodeArgs &a, void *stream, bool only_last);
 
 // {frames, frame errors, bit errors, iterations, early stops} of a batch (all device pointers), one launch
 int launch_batch_counters(const uint32_t *iters, const uint32_t *bit_errors, uint64_t n, uint32_t max_iters, int early_term,

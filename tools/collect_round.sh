@@ -20,10 +20,11 @@ if [ "$part" = a ] || [ "$part" = all ]; then
 fi
 if [ "$part" = b ] || [ "$part" = all ]; then
     timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/stats" -o run --output-format csv -- \
-        python3 bench.py --steps 10 --warmup 10 --no-cpu-baseline --no-pmc > "$out/bench_stats.log" 2>&1 || echo "stats pass failed"
+        python3 bench.py --steps 10 --warmup 10 --no-cpu-baseline --no-pmc --no-other-configs > "$out/bench_stats.log" 2>&1 || echo "stats pass failed"
     find "$out/stats" -name "*kernel_trace.csv" -delete
     timeout -k 10 300 python3 tools/shard_probe.py --config 2 --worlds 1,2,4,8 --out "$out/shard_cost_cfg2.jsonl" > "$out/shard2.log" 2>&1 || echo "shard probe (config 2) failed"
     timeout -k 10 300 python3 tools/shard_probe.py --config 4 --worlds 1,2,4,8 --out "$out/shard_cost_cfg4.jsonl" > "$out/shard4.log" 2>&1 || echo "shard probe (config 4) failed"
+    timeout -k 10 300 python3 tools/shard_probe.py --config 2 --gen --worlds 1,2,4,8 --steps 30 --out "$out/shard_cost_cfg2_gen.jsonl" > "$out/shard2g.log" 2>&1 || echo "shard probe (config 2, -G) failed"
     echo "probes done"
     timeout -k 10 500 python3 tools/fast_mode_report.py > "$out/fast_mode_report.jsonl" 2> "$out/fast_mode_report.err" || echo "fast mode report failed"
     echo "fast mode report done"

@@ -22,6 +22,7 @@ ap.add_argument("--rank", default="last")
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--out", default="")
+ap.add_argument("--gen", action="store_true", help="with the generator matrix (tests/golden/g.txt; h.txt only): the encoder's share of a step")
 args = ap.parse_args()
 w = workloads.get(args.config)
 B = w["batch"]
@@ -30,7 +31,7 @@ stream = torch.cuda.current_stream().cuda_stream
 lines = []
 for W in [int(x) for x in args.worlds.split(",")]:
     r = W - 1 if args.rank == "last" else min(int(args.rank), W - 1)
-    dec = libldpc_amd.HipDecoder(workloads.code_path(w))
+    dec = libldpc_amd.HipDecoder(workloads.code_path(w), os.path.join("tests", "golden", "g.txt") if args.gen else "")
     dec.set_profiling(True)
     comm = libldpc_amd.Comm(r, W, echo=True)
     cap = dec.shard_capacity(B * W, W)
@@ -54,7 +55,7 @@ for W in [int(x) for x in args.worlds.split(",")]:
             "decode_kernel_ms": dec.last_ms(0), "noise_stream_ms": dec.last_ms(1), "host_wait_noise_ms": dec.last_ms(3),
             "host_in_exchange_ms": dec.last_ms(2), "jump_tasks_per_step": (dec.jump_tasks - j0) / args.steps,
             "frames_per_step_this_rank": frames / args.steps, "frames_per_s_this_rank": frames / dt,
-            "exchange": "echo (one process standing in for the rank; no wire)"}
+            "generator_matrix": bool(args.gen), "exchange": "echo (one process standing in for the rank; no wire)"}
     print(json.dumps(line), flush=True)
     lines.append(line)
     comm.close()

@@ -215,6 +215,10 @@ void ldpc_hip_comm_destroy(ldpc_hip_comm *comm);
    bound: when a rank does not arrive within LDPC_AMD_COMM_TIMEOUT_S seconds (default 60; ncclCommInitRank in
    ldpc_hip_comm_create likewise) the call fails on the ranks that wait for it and the communicator is unusable from then on */
 int ldpc_hip_comm_allgather(ldpc_hip_comm *comm, const void *send, void *recv, uint64_t bytes);
+/* the plan of the fused form of the first ratio launch (libldpc_amd/csrc/fused_rule.h decides which codes
+   take it): info = {the code qualifies, message slots, variable-node blocks per wave, leaf calls per wave, the small
+   instantiation applies, check-node calls per wave + 1, the code has shortened bits, entries of the slot table} */
+void ldpc_hip_fused_plan_info(const ldpc_hip_ctx *ctx, int64_t info[8]);
 /* the steps of the layered schedule of the non-parity modes 2 / 3 (host only): step_of_row[mc] = the step each check node
    is processed in; returns the number of steps, -1 when the schedule does not take the code */
 int ldpc_hip_selftest_layer_plan(ldpc_hip_ctx *ctx, int32_t *step_of_row);

@@ -91,6 +91,8 @@ def load_library(path=LIB_PATH):
     L.ldpc_hip_comm_destroy.argtypes = [vp]
     L.ldpc_hip_comm_allgather.restype = i32
     L.ldpc_hip_comm_allgather.argtypes = [vp, vp, vp, u64]
+    L.ldpc_hip_fused_plan_info.restype = None
+    L.ldpc_hip_fused_plan_info.argtypes = [vp, vp]
     L.ldpc_hip_selftest_layer_plan.restype = i32
     L.ldpc_hip_selftest_layer_plan.argtypes = [vp, vp]
     L.ldpc_hip_selftest_place.restype = i32
@@ -239,6 +241,12 @@ class HipDecoder:
 
     def set_bec_compat(self, on):
         self.lib.ldpc_hip_set_bec_compat(self.ctx, int(on))
+
+    def fused_plan(self):
+        """Summary of the plan of the fused form (include/ldpc_amd.h, ldpc_hip_fused_plan_info)."""
+        info = (ct.c_int64 * 8)()
+        self.lib.ldpc_hip_fused_plan_info(self.ctx, info)
+        return dict(zip(("ok", "n_slots", "vnb", "cnl", "small", "calls_stride", "has_shortened", "table_entries"), [int(v) for v in info]))
 
     def set_fast_mode(self, on):
         """Opt-in NON-PARITY mode: sum-product with binary32 messages (include/ldpc_amd.h)."""

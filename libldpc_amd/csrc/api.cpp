@@ -570,6 +570,13 @@ int ldpc_hip_comm_allgather(ldpc_hip_comm *comm, const void *send, void *recv, u
     return guarded([&] { comm->comm->all_gather(send, recv, bytes); });
 }
 
+void ldpc_hip_fused_plan_info(const ldpc_hip_ctx *ctx, int64_t info[8])
+{
+    const FusedPlan &f = ctx->eng->fused_plan();
+    info[0] = f.ok ? 1 : 0, info[1] = f.n_slots, info[2] = f.vnb, info[3] = f.cnl, info[4] = f.wide_exclusive ? 1 : 0;
+    info[5] = f.calls_stride, info[6] = f.has_shortened ? 1 : 0, info[7] = static_cast<int64_t>(f.vn_slot.size());
+}
+
 int ldpc_hip_selftest_layer_plan(ldpc_hip_ctx *ctx, int32_t *step_of_row)
 {
     int n = -1;

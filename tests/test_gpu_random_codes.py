@@ -168,3 +168,84 @@ def test_edge_case_batches():
     r = d.stream_decode(0, want=("iters",))
     assert r["iters"].shape == (0,)
     assert d.decode_batch(np.zeros((0, d.nc)))["iters"].shape == (0,)
+
+
+def make_fused_code(path, rng, cn_spec, vn_degs, puncture=(), shorten=()):
+    """A random code the fused rule takes (libldpc_amd/csrc/fused_rule.h): check nodes of degree 2..4 with at most one leaf
+    each.  cn_spec = [(degree, has_leaf, how many)]; vn_degs = degrees (>= 2) of the other variable nodes, whose sockets
+    must equal the check nodes' non-leaf sockets.  Columns: the other variable nodes first, then the leaves; rows shuffled."""
+    rows = []
+    for deg, leaf, count in cn_spec:
+        rows += [(deg, leaf)] * count
+    rng.shuffle(rows)
+    sockets = sum(d - l for d, l in rows)
+    assert sockets == sum(vn_degs), (sockets, sum(vn_degs))
+    cols = np.repeat(np.arange(len(vn_degs)), vn_degs)
+    owner = np.repeat(np.arange(len(rows)), [d - l for d, l in rows])
+    rng.shuffle(cols)
+    for _ in range(500):
+        key = owner.astype(np.int64) * len(vn_degs) + cols
+        _, first = np.unique(key, return_index=True)
+        dup = np.setdiff1d(np.arange(key.size), first)
+        if dup.size == 0:
+            break
+        other = rng.integers(0, key.size, dup.size)
+        cols[dup], cols[other] = cols[other].copy(), cols[dup].copy()
+    else:
+        raise AssertionError("could not repair duplicate edges")
+    lines, leaf_col = [], len(vn_degs)
+    if puncture:
+        lines.append(f"puncture [{len(puncture)}]: " + " ".join(map(str, puncture)))
+    if shorten:
+        lines.append(f"shorten [{len(shorten)}]: " + " ".join(map(str, shorten)))
+    for i, (deg, leaf) in enumerate(rows):
+        mine = list(cols[owner == i])
+        if leaf:
+            mine.append(leaf_col)
+            leaf_col += 1
+        rng.shuffle(mine)  # the leaf and the degree-2 neighbours anywhere in the row's file order
+        for c in mine:
+            lines.append(f"{i} {c}")
+    open(path, "w").write("\n".join(lines))
+    return path
+
+
+FUSED_CASES = [
+    # small instantiation shapes besides h.txt: partly filled blocks, a wide block of degree 7, degree-2 check nodes
+    ("fused_small", [(2, 0, 30), (3, 0, 50), (3, 1, 40), (4, 0, 20), (4, 1, 70)], [2] * 150 + [7] * 40, (3, 200), ()),
+    # the small instantiation on another shape: one leaf class, blocks of degree 3 and 5 through register-held offsets
+    ("fused_small_one_class", [(4, 1, 128), (3, 0, 100)], [3] * 128 + [5] * 60, (), ()),
+    # the general instantiation: many degree-2 blocks (eight slots per wave), every leaf class (two leaf calls per wave), a
+    # block of degree 20 (slot table: wider than the register-held offsets) and blocks of degree 3 and 5 beside a wide one
+    ("fused_general", [(2, 0, 60), (3, 0, 300), (3, 1, 120), (4, 0, 200), (4, 1, 160)],
+     [2] * 600 + [3] * 200 + [5] * 60 + [20] * 10 + [12] * 10 + [6] * 20, (0, 1, 900), (5,)),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
+def test_fused_form_on_random_codes(case, tmp_path):
+    """The fused kernels (kernels_fused.hip) beyond the one code the headline runs: every instantiation (small / general, with
+    and without the LLR output), the slot-table path, degree-2 check nodes, partly filled blocks, leaves and degree-2
+    neighbours anywhere in a row's file order, punctured and shortened columns — sum-product with early termination (three
+    launches: frames escape at high SNR), without (hand-over), min-sum without early termination, BSC; bit for bit against
+    the det-mode oracle, which must have taken the fused form too (fused_rule.h is shared; the plan reports it)."""
+    import libldpc_amd
+    name, cn_spec, vn_degs, punct, short = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    path = make_fused_code(str(tmp_path / f"{name}.txt"), rng, cn_spec, vn_degs, punct, short)
+    code = orc.Code(path)
+    d = libldpc_amd.HipDecoder(path)
+    assert (d.nc, d.mc, d.nnz) == (code.nc, code.mc, code.nnz) and d.residency == "lds"
+    assert d.fused_plan()["ok"] == 1, d.fused_plan()
+    if name == "fused_general":
+        assert d.fused_plan()["vnb"] > 4 and d.fused_plan()["cnl"] == 2, d.fused_plan()
+    for ch, x, ms, early, iters in (("AWGN", 2.0, False, True, 25), ("AWGN", 6.0, False, True, 25), ("AWGN", 14.0, False, True, 20),
+                                    ("AWGN", 3.0, False, False, 30), ("AWGN", 8.0, False, False, 45), ("AWGN", 2.0, True, False, 20),
+                                    ("AWGN", 1.0, True, True, 15), ("BSC", 0.04, False, True, 25)):
+        o = code.run_frames(ch, x, seed=4, skip=2, count=6, min_sum=ms, early_term=early, iters=iters, math=orc.MATH_DET)
+        for want in (OUT, ("iters", "bit_errors", "hard")):
+            d.stream_begin(ch, 4, x)
+            d.stream_skip(2)
+            r = d.stream_decode(6, early_term=early, iterations=iters, decoding="BP_MS" if ms else "BP", want=want)
+            for k in want:
+                assert np.array_equal(r[k], o[k].astype(r[k].dtype)), (name, ch, x, ms, early, k, len(want))

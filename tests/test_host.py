@@ -223,6 +223,18 @@ def test_sharded_step_placement_two_ranks_gloo(tmp_path):
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+def test_fused_plan_of_the_test_code(lib, h8k_file):
+    """The plan of the fused form (plan.cpp, build_fused_plan; the rule: fused_rule.h) for the reference's test code: 2 944
+    message slots (the 512 edges that end in a leaf have none), at most four variable-node blocks and one leaf call per
+    wave, the small instantiation — and none at all for the (3,6)-regular code (check nodes of degree 6)."""
+    import libldpc_amd
+    d = libldpc_amd.HipDecoder(orc.H_TXT)
+    f = d.fused_plan()
+    assert f["ok"] == 1 and f["n_slots"] == 3456 - 512 and f["vnb"] == 4 and f["cnl"] == 1 and f["small"] == 1, f
+    assert f["has_shortened"] == 0 and f["table_entries"] <= 1, f
+    assert libldpc_amd.HipDecoder(h8k_file).fused_plan()["ok"] == 0
+
+
 def test_layer_plan_matches_its_restatement(lib):
     """The steps of the layered schedule (non-parity modes 2 / 3): the product's plan (plan.cpp, build_layer_plan) and the
     oracle's independent restatement put every check node of h.txt into the same step — the mirror the GPU test of the

@@ -670,6 +670,18 @@ void Engine::upload_plan()
         std::vector<uint32_t> cp(code_->G.cptr.begin(), code_->G.cptr.end()), cr(code_->G.crow.begin(), code_->G.crow.end());
         g_col_ptr_ = static_cast<const uint32_t *>(up(cp.data(), cp.size() * 4));
         g_col_row_ = static_cast<const uint32_t *>(up(cr.data(), cr.size() * 4));
+        const int kc = code_->kc(), words = (kc + 63) / 64;
+        if (kc > 0 && words <= 4 && code_->G.rows <= kc)
+        {
+            std::vector<uint64_t> mask(static_cast<size_t>(p.nc) * words, 0);
+            for (int j = 0; j < code_->G.cols && j < p.nc; ++j)
+                for (int q = code_->G.cptr[j]; q < code_->G.cptr[j + 1]; ++q)
+                {
+                    const int r = code_->G.crow[q];
+                    mask[static_cast<size_t>(j) * words + r / 64] ^= 1ull << (r % 64); // (a repeated entry cancels, as in the walk)
+                }
+            g_mask_ = static_cast<const uint64_t *>(up(mask.data(), mask.size() * 8));
+        }
     }
     dev_.lds_bytes = static_cast<uint32_t>(p.lds_bytes);
 }
@@ -1011,6 +1023,7 @@ const uint8_t *Engine::encode_frames(uint64_t n, bool want_codewords, void *stre
     e.words = static_cast<int>((kc + 63) / 64);
     e.g_col_ptr = g_col_ptr_;
     e.g_col_row = g_col_row_;
+    e.g_mask = g_mask_;
     e.g_cols = code_->G.cols;
     e.info_raw = info_.generate(info_pos_, n * kc, stream);
     e.prefix = static_cast<uint64_t *>(enc_prefix_.reserve(8 * n * e.words));
@@ -1049,6 +1062,7 @@ const uint8_t *Engine::encode_frames_sharded(Comm &comm, uint64_t before, uint64
     EncodeArgs e{};
     e.nc = static_cast<int>(nc), e.kc = static_cast<int>(kc), e.words = words;
     e.g_col_ptr = g_col_ptr_, e.g_col_row = g_col_row_, e.g_cols = code_->G.cols;
+    e.g_mask = g_mask_;
     e.cw_prev = prev;
     e.cw_last = static_cast<uint8_t *>(cw_next_.reserve(nc));
     std::vector<uint64_t> mine(words, 0), all(static_cast<size_t>(words) * comm.world());

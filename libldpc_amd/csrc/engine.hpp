@@ -301,6 +301,7 @@ class Engine
     DeviceBuffer cw_run_, cw_next_, cw_frames_, cw_before_, enc_prefix_;
     uint64_t last_enc_n_ = 0;   // frames of the last encode_frames call that produced cw_frames_
     const uint32_t *g_col_ptr_ = nullptr, *g_col_row_ = nullptr;
+    const uint64_t *g_mask_ = nullptr; // the columns of G as bit masks, [nc][words] (kernels.hpp, EncodeArgs::g_mask)
     DeviceBuffer slabs_[2], slab_cum_[2], nz_counts_, nz_result_, nz_locate_, nz_cum_skip_, nz_raw_, nz_lookback_;
     // the AWGN noise generator runs on its own stream so that the normals of batch s+1 are produced while
     // the decode kernel of batch s drains; the slabs are double-buffered, events order the two streams

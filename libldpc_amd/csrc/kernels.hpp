@@ -283,6 +283,9 @@ struct EncodeArgs
     // sharded encoding: XOR of the info words of the step's frames before this rank's (0 for a whole stream): joins every
     // prefix of the batch (the codeword accumulates linearly over the frames: channel.cpp:44-60, sparse.h:163-172)
     const uint64_t *base;      // [words] device, or nullptr
+    // the columns of G as bit masks over the info word, [nc][words] (zero rows beyond g_cols), or nullptr: with them and
+    // words <= 4 a codeword bit is a handful of AND / popcount instead of a walk over the column's entries
+    const uint64_t *g_mask;
 };
 int launch_encode(const EncodeArgs &a, void *stream);
 // the two halves of launch_encode by themselves (sharded encoding): info words + their running XOR over the batch; the

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(kGenThreads *kGenChunks) void mt_generate_kernel(co
                                                                               uint32_t n_chunks)
 {
     __shared__ uint64_t edge[kGenChunks][2][4][2]; // [chunk of the workgroup][parity][w0 l0, w0 l1, w1 l0, w2 l0][L, H]
+#ifdef LDPC_AMD_GEN_PRIO
+    __builtin_amdgcn_s_setprio(LDPC_AMD_GEN_PRIO); // (experiments: the generator's few waves beside the decode kernel's, which run at 3)
+#endif
     const int t = threadIdx.x % kGenThreads, sub = threadIdx.x / kGenThreads;
     const int lane = t & 63, w = t >> 6;
     const uint64_t c = static_cast<uint64_t>(blockIdx.x) * kGenChunks + sub;

@@ -654,6 +654,7 @@ void Engine::upload_plan()
         const FusedPlan &f = fused_plan_;
         dev_fused_.n_slots = f.n_slots, dev_fused_.vnb = f.vnb, dev_fused_.cnl = f.cnl, dev_fused_.calls_stride = f.calls_stride;
         dev_fused_.has_shortened = f.has_shortened ? 1 : 0;
+        dev_fused_.need_lambda = f.need_lambda ? 1 : 0;
         dev_fused_.wide_exclusive = f.wide_exclusive ? 1 : 0;
         std::memcpy(dev_fused_.vn_prog, f.vn_prog, sizeof f.vn_prog);
         // the message slots; the prologue stages one 16-byte entry per transmitted bit or column (+ 2) in the same space
@@ -1305,7 +1306,7 @@ void Engine::fill_slab_args(DecodeArgs &a, const NoisePass &np, uint64_t pair_or
     a.n_slabs = np.n_slabs;
     a.slab_pairs_inv = static_cast<float>(1.0 / (static_cast<double>(noise_.st.chunk_trials()) * 0.7853981633974483));
     a.pair_origin = pair_origin;
-    a.sigma = sigma_, a.sigma2 = sigma2_;
+    a.sigma = sigma_, a.sigma2 = sigma2_, a.inv_sigma2 = 1.0 / sigma2_;
     a.shorten_llr = 99999.9; // channel.cpp:83
     a.pairs_buffer = buf;
 }

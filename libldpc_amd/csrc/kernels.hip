@@ -2163,6 +2163,15 @@ __global__ __launch_bounds__(256) void division_selftest_kernel(uint64_t n, uint
         const double a = operand(), b = operand();
         volatile double bv = b; // keep the compiler from folding the two forms together
         bad += dm_bits(dm_ratio_div(a, b)) != dm_bits(a / bv);
+        // dm_div_by (detmath.h): numerators of either sign up to 2^8 over divisors in [2^-7, 2^7] with THEIR correctly rounded
+        // reciprocal (here: the device's own IEEE division, which is correctly rounded) — the channel's 2 y / sigma^2
+        const uint64_t m2 = next() >> 12, e2 = 1023 - 7 + (next() >> 33) % 15;
+        const double d = dm_from_bits((e2 << 52) | m2);
+        volatile double dv = d;
+        const double rcp = 1.0 / dv;
+        const uint64_t m3 = next() >> 12, e3 = 1023 - 60 + (next() >> 33) % 69, s3 = next() >> 63;
+        const double num = dm_from_bits((s3 << 63) | (e3 << 52) | m3);
+        bad += dm_bits(dm_div_by(num, d, rcp)) != dm_bits(num / dv);
     }
     if (bad)
         atomicAdd(mismatches, bad);

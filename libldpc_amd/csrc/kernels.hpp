@@ -64,6 +64,7 @@ struct DecodeArgs
     uint64_t normal_base;     // index of this batch's first normal in the stream
     int pairs_buffer;         // host bookkeeping: which of the engine's two slab buffers `pairs` points into
     double sigma, sigma2; // sqrt(sigma2), sigma2 = 10^(-snr/10)
+    double inv_sigma2;    // 1 / sigma2, correctly rounded (host division): detmath.h, dm_div_by
     double shorten_llr;   // 99999.9 (AWGN) or delta (BSC)
     // kModeBsc: raw draws, one per transmitted bit: raw[frame*nct + i]
     const uint64_t *raw;
@@ -133,6 +134,7 @@ struct DevFusedPlan
 {
     int n_slots, vnb, cnl, calls_stride;
     int has_shortened;
+    int need_lambda; // a column that is transmitted or shortened has three or more edges: the prologue stages lambda_ch too
     int wide_exclusive;
     uint32_t vn_prog[kDecodeWaves]; // plan.hpp, FusedPlan::vn_prog
     uint32_t lds_bytes;          // dynamic LDS per frame: the message slots, or the staging area of the prologue if larger

@@ -344,7 +344,7 @@ __device__ __forceinline__ bool stage_channel(const DecodeArgs &a, const DevFuse
                 const double noise = dm_from_bits(w) * a.sigma + 0.0; // channel.cpp:62-68
                 const double xs = cw ? static_cast<double>(1 - 2 * xb) : 1.0;
                 const double y = noise + xs;
-                const double L = 2 * y / a.sigma2; // channel.cpp:88-92
+                const double L = dm_div_by(2 * y, a.sigma2, a.inv_sigma2); // (2 y) / sigma^2, channel.cpp:88-92: the IEEE quotient
                 if (dump)
                     dump[col] = L;
                 put(i, L);
@@ -398,11 +398,13 @@ __device__ __forceinline__ void fused_body(const DecodeArgs &a, const DevFusedPl
     const int n_stage = given ? nc : nct;
     double2 *stage = reinterpret_cast<double2 *>(lds);
     {
+        // rho_ch = e^L for every value; lambda_ch = e^-L beside it only where a node of degree >= 3 will ask for it (the n = 1024
+        // code: nowhere — its wide nodes are punctured): no division in the prologue
+        const bool need_lambda = F.need_lambda != 0 || given;
         auto put = [&](int s, double L) {
             if (!(__builtin_fabs(L) <= DM_RATIO_LLR_LIMIT))
                 t.hmax = 0xFFFFFFFFu; // the frame leaves the ratio form at once
-            const double lam = dm_exp_clamped(0.0 - L);
-            stage[s] = double2{lam, dm_ratio_div(1.0, lam)};
+            stage[s] = double2{need_lambda ? dm_exp_clamped(0.0 - L) : 1.0, dm_exp_clamped(L)};
         };
         if (!stage_channel(a, F, frame, tid, put))
             t.hmax = 0xFFFFFFFFu;

@@ -672,6 +672,9 @@ FusedPlan build_fused_plan(const LdpcCode &code, const Plan &plan)
         if (c >= 0 && c < H.cols && plan.rank_kind[plan.col_rank[c]] == 2)
             col_entry[c] = static_cast<uint32_t>(plan.nct);
     f.has_shortened = !code.shorten.empty();
+    for (int c = 0; c < H.cols; ++c) // (punctured and never-written columns have L = 0: lambda = rho = 1, staged as constants)
+        if (cdeg(c) >= 3 && col_entry[c] <= static_cast<uint32_t>(plan.nct))
+            f.need_lambda = true;
 
     f.vn_desc.assign(static_cast<size_t>(W) * kFusedVnSlots * 4, 0);
     f.lane_tab.assign(static_cast<size_t>(W) * kFusedLaneRows * kWaveSize, 0);

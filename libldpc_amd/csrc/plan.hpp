@@ -210,6 +210,7 @@ struct FusedPlan
     int n_slots = 0;     // message slots
     int vnb = 0, cnl = 0; // largest number of variable-node blocks / of leaf calls any wave holds
     bool has_shortened = false;
+    bool need_lambda = false; // a transmitted or shortened column of degree >= 3: its node keeps lambda_ch (detmath.h "Fused form")
     // a wave that serves a block through register-held offsets (slot 0, degree 3..15) serves no other, and no block goes
     // through the slot table: what the small instantiation of the kernel is compiled for
     bool wide_exclusive = false;

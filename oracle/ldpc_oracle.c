@@ -862,7 +862,7 @@ static int dec_decode_fused(dec_t *d)
         double L = d->llr_in[i];
         escaped |= !(fabs(L) <= DM_RATIO_LLR_LIMIT);
         lam[i] = dm_exp_clamped(0.0 - L);
-        rho[i] = 1.0 / lam[i];
+        rho[i] = dm_exp_clamped(L); /* (the fused form takes both from the exponential: no division in its prologue) */
         for (int p = H->cptr[i]; p < H->cptr[i + 1]; ++p)
             d->v2c[H->cedge[p]] = rho[i];
     }

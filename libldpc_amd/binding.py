@@ -331,7 +331,7 @@ class HipDecoder:
         return bad.value
 
     MATH_FNS = ("exp", "log", "boxplus", "ratio_div", "ratio_rho", "ratio_lambda", "e_combine", "exp_clamped", "boxplus_exp",
-                "boxplus_log", "cn_ratio3", "cn_ratio4", "cn_ratio5", "cn_ratio6", "cn_ratio8", "cn_llr4", "cn_llr6", "cn_ratio3s", "cn_ratio4s")
+                "boxplus_log", "cn_ratio3", "cn_ratio4", "cn_ratio5", "cn_ratio6", "cn_ratio8", "cn_llr4", "cn_llr6", "cn_ratio3s", "cn_ratio4s", "cn_ratio6s")
 
     def selftest_math(self, fn, a, b=None):
         """The device arithmetic of detmath.h / device_cn.hpp on host arrays: fn is a name of MATH_FNS."""

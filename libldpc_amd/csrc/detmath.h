@@ -594,6 +594,54 @@ DM_FN uint32_t dm_cn4_shared(double *v)
     return h01 > h23 ? h01 : h23;
 }
 
+/*
+ * Degree 6 (the (3,6)-regular codes' check node): the six outputs of the fraction form above (dm_frac: same partial results,
+ * same rescaling, same numerators n_k and denominators d_k as the separately divided node) in two triples, outputs 0,1,2 and
+ * 3,4,5, each triple with ONE reciprocal of the product of its three denominators: 2 reciprocals and 32 further
+ * instructions where six divisions take 6 and 42.  Returns the larger upper word of the two products (range rule as above:
+ * below 2^897; measured on the n = 8192 code from 1 to 6 dB: at most 2^610 — all six in one product reach 2^1095).
+ */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define DM_TIE5(a, b, c, d, e) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e))
+#else
+#define DM_SCHED_FENCE() ((void)0)
+#define DM_TIE5(a, b, c, d, e) ((void)0)
+#endif
+DM_FN uint32_t dm_cn6_shared(double *v)
+{
+    /* (the fences keep the device compiler from interleaving the stages — of this node and of its neighbours in a register-
+       resident kernel — which would need more registers than there are; they change no value) */
+    const dm_frac B4 = dm_frac_first(v[5], v[4]);
+    const dm_frac B3 = dm_frac_norm(dm_frac_step(B4, v[3]));
+    const dm_frac B2 = dm_frac_step(B3, v[2]);
+    DM_SCHED_FENCE();
+    const double n0 = DM_FMA(B2.d, v[1], B2.n), d0 = DM_FMA(B2.n, v[1], B2.d); /* B[1] = B[2] [+] v[1] */
+    const double n1 = DM_FMA(B2.d, v[0], B2.n), d1 = DM_FMA(B2.n, v[0], B2.d); /* F[0] [+] B[2] */
+    dm_frac F = dm_frac_first(v[0], v[1]);                                      /* F[1] */
+    const double n2 = DM_FMA(F.n, B3.d, F.d * B3.n), d2 = DM_FMA(F.n, B3.n, F.d * B3.d); /* F[1] [+] B[3] */
+    F = dm_frac_norm(dm_frac_step(F, v[2])); /* F[2] */
+    DM_SCHED_FENCE();
+    const double p01 = d0 * d1, P = p01 * d2;
+    const double r = dm_ratio_div(1.0, P);
+    const double i2 = r * p01, t = r * d2;
+    v[0] = n0 * (t * d1), v[1] = n1 * (t * d0), v[2] = n2 * i2;
+    DM_TIE5(v[0], v[1], v[2], F.n, F.d); /* the second triple starts when the first has been delivered */
+    DM_SCHED_FENCE();
+    const double n3 = DM_FMA(F.n, B4.d, F.d * B4.n), d3 = DM_FMA(F.n, B4.n, F.d * B4.d); /* F[2] [+] B[4] */
+    F = dm_frac_step(F, v[3]);                                                            /* F[3] */
+    const double n4 = DM_FMA(F.d, v[5], F.n), d4 = DM_FMA(F.n, v[5], F.d);               /* F[3] [+] B[5] */
+    const double n5 = DM_FMA(F.d, v[4], F.n), d5 = DM_FMA(F.n, v[4], F.d);               /* F[4] = F[3] [+] v[4] */
+    DM_SCHED_FENCE();
+    const double p34 = d3 * d4, Q = p34 * d5;
+    const double s = dm_ratio_div(1.0, Q);
+    const double i5 = s * p34, u = s * d5;
+    v[3] = n3 * (u * d4), v[4] = n4 * (u * d3), v[5] = n5 * i5;
+    DM_SCHED_FENCE();
+    const uint32_t hP = (uint32_t)(dm_bits(P) >> 32), hQ = (uint32_t)(dm_bits(Q) >> 32);
+    return hP > hQ ? hP : hQ;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Fused form (round 4): the first of the three launches of sum-product WITH early termination, for codes whose check
  * nodes have 2..4 edges and at most one degree-1 neighbour each (fused_rule.h: a property of the code alone; the n = 1024

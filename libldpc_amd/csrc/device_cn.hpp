@@ -135,10 +135,18 @@ __device__ __forceinline__ void cn_core(double (&v)[D])
 // partial results stay undivided fractions).
 // SHARED (early-termination kernels): nodes of degree 3 and 4 take one reciprocal of the product of their denominators
 // (detmath.h, "Shared-reciprocal check nodes"); the product's range check joins the frame's escape tracking (escaped).
-template <int D, bool SHARED = false>
-__device__ __forceinline__ void cn_ratio(double (&v)[D], uint32_t *escaped = nullptr)
+// SHARED6 (early-termination kernels of codes the LDS-resident decoder does not take): nodes of degree 6 take two
+// reciprocals for their six outputs (dm_cn6_shared); that range check is tracked in *escaped6, which the caller lets count
+// only once the frame has gone on to the variable-node pass (detmath.h).
+template <int D, bool SHARED = false, bool SHARED6 = false>
+__device__ __forceinline__ void cn_ratio(double (&v)[D], uint32_t *escaped = nullptr, uint32_t *escaped6 = nullptr)
 {
-    if constexpr (SHARED && D == 3)
+    if constexpr (SHARED6 && D == 6)
+    {
+        const uint32_t h = dm_cn6_shared(v);
+        DM_SHARED_TRACK(*escaped6, h);
+    }
+    else if constexpr (SHARED && D == 3)
     {
         const uint32_t h = dm_cn3_shared(v);
         DM_SHARED_TRACK(*escaped, h);

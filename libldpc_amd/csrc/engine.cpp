@@ -458,6 +458,9 @@ Engine::Engine(const std::string &pc_file, const std::string &gen_file, int devi
     plan_ = build_plan(*code_);
     if (plan_.lds_ok && !std::getenv("LDPC_AMD_NO_FUSED")) // (the variable: experiments only — results change by ulps)
         fused_plan_ = build_fused_plan(*code_, plan_);
+    if (!plan_.lds_ok)
+        for (int r = 0; r < code_->H.rows && !shared6_; ++r)
+            shared6_ = code_->H.rptr[r + 1] - code_->H.rptr[r] == 6;
     if (!plan_.lds_ok) // register-resident decoder: the smallest register tile the code fits
     {
         // One frame per CU (1024 threads, 128 VGPRs, 160 KB mailbox) first: measured 1.37x faster on the n=8192
@@ -919,8 +922,10 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
             a.redo_iter_in = redo + 1 + n;
             a.handover_llr = fused_handover_used ? 1 : 0;
         }
-        else if (plan_.lds_ok)
+        else if (plan_.lds_ok || shared6_)
         {
+            // (codes the LDS-resident decoder does not take: the same three launches when the code has check nodes of degree 6,
+            // which share reciprocals in the first launch of the register- and memory-resident decoders — detmath.h, dm_cn6_shared)
             // The first launch ran the shared-reciprocal check nodes (detmath.h), whose denominator products leave their
             // range in a few frames per ten thousand at the waterfall (strongly converged frames): those are decoded again
             // from scratch with every output divided separately — the ratio form still, a twentieth of a millisecond for a

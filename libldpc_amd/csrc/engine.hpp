@@ -273,6 +273,7 @@ class Engine
     Plan plan_;
     RegPlan reg_plan_;
     Reg2Plan reg2_plan_;
+    bool shared6_ = false; // not LDS-resident and a check node of degree 6: three launches with early termination (dm_cn6_shared)
     FusedPlan fused_plan_; // fused form of the first ratio launch (kernels_fused.hip); ok = the code qualifies (fused_rule.h)
     DevFusedPlan dev_fused_{};
     LayerPlan layer_plan_;

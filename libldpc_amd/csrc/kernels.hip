@@ -304,9 +304,10 @@ __device__ __forceinline__ double with_sign(double mag, uint32_t sign_hi) // mag
     return dm_from_bits(dm_bits(mag) | (static_cast<uint64_t>(sign_hi) << 32));
 }
 
-// SH: the shared-reciprocal form of degree-3 and degree-4 nodes (detmath.h); esc = the frame's escape tracking, which the
-// nodes' denominator products join
-template <int D, bool SH>
+// SH = 1: the shared-reciprocal form of degree-3 and degree-4 nodes (detmath.h); esc = the frame's escape tracking, which the
+// nodes' denominator products join.  SH = 2: that of degree-6 nodes (codes the LDS-resident decoder does not take); esc = the
+// accumulator the caller merges into the frame's tracking once the frame has gone on to the variable-node pass
+template <int D, int SH>
 __device__ __forceinline__ uint32_t cn_update_ratio(double *m, int stride, uint32_t &esc)
 {
     double v[D];
@@ -319,16 +320,16 @@ __device__ __forceinline__ uint32_t cn_update_ratio(double *m, int stride, uint3
         par ^= sg[j];
         v[j] = __builtin_fabs(x);
     }
-    cn_ratio<D, SH>(v, &esc);
+    cn_ratio<D, SH == 1, SH == 2>(v, &esc, &esc);
 #pragma unroll
     for (int j = 0; j < D; ++j)
         m[j * stride] = with_sign(v[j], sg[j]);
     return par;
 }
 
-template <int MAXD, bool SH>
+template <int MAXD, int SH>
 __device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b, int lane, uint32_t &esc);
-template <int MAXD, bool SH>
+template <int MAXD, int SH>
 __device__ __forceinline__ uint32_t cn_block_ratio_fwd(double *msg, const CnBlock b, int lane, uint32_t &esc)
 {
     return cn_block_ratio<MAXD, SH>(msg, b, lane, esc);
@@ -336,7 +337,7 @@ __device__ __forceinline__ uint32_t cn_block_ratio_fwd(double *msg, const CnBloc
 
 // two full blocks (64 nodes each) of the same degree at once: two independent chains per lane hide the latency of
 // the divisions and of the LDS round trip; the constant stride lets the loads pair up (ds_read2st64_b64)
-template <int D0, int D1, bool SH>
+template <int D0, int D1, int SH>
 __device__ __forceinline__ uint32_t cn_update_ratio2(double *m0, double *m1, uint32_t &esc)
 {
     double v0[D0], v1[D1];
@@ -357,8 +358,8 @@ __device__ __forceinline__ uint32_t cn_update_ratio2(double *m0, double *m1, uin
         par1 ^= g1[j];
         v1[j] = __builtin_fabs(x1);
     }
-    cn_ratio<D0, SH>(v0, &esc);
-    cn_ratio<D1, SH>(v1, &esc);
+    cn_ratio<D0, SH == 1, SH == 2>(v0, &esc, &esc);
+    cn_ratio<D1, SH == 1, SH == 2>(v1, &esc, &esc);
 #pragma unroll
     for (int j = 0; j < D0; ++j)
         m0[j * kWaveSize] = with_sign(v0[j], g0[j]);
@@ -368,7 +369,7 @@ __device__ __forceinline__ uint32_t cn_update_ratio2(double *m0, double *m1, uin
     return par0 | par1;
 }
 
-template <int MAXD, bool SH>
+template <int MAXD, int SH>
 __device__ __forceinline__ uint32_t cn_pair_ratio(double *msg, uint32_t off0, uint32_t off1, int deg0, int deg1, int lane, uint32_t &esc)
 {
     double *m0 = msg + off0 + lane, *m1 = msg + off1 + lane;
@@ -401,7 +402,7 @@ __device__ __forceinline__ uint32_t cn_pair_ratio(double *msg, uint32_t off0, ui
 }
 
 // returns the parity (bit 31) of the hard decisions on this lane's check node
-template <int MAXD, bool SH>
+template <int MAXD, int SH>
 __device__ __forceinline__ uint32_t cn_block_ratio(double *msg, const CnBlock b, int lane, uint32_t &esc)
 {
     if (lane >= b.count)
@@ -1317,7 +1318,11 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
             // (not in the hand-over kernel: its frames iterate on after they have converged, the denominator products
             // overflow before the hand-over threshold is reached, and every overflow is a frame decoded again — measured:
             // 31.7 ms per batch instead of 13.2)
-            constexpr bool SH = LDS_RESIDENT && !HANDOVER && !SEPARATE;
+            // (memory-resident decoder with early termination: degree-6 nodes share reciprocals, mode 2; their range check counts
+            // only when the frame goes on to the variable-node pass, so it is kept apart until the checks below have passed)
+            constexpr int SH = (HANDOVER || SEPARATE) ? 0 : (LDS_RESIDENT ? 1 : (MAXD >= 6 ? 2 : 0));
+            [[maybe_unused]] uint32_t esc6 = 0;
+            uint32_t &cn_esc = SH == 2 ? esc6 : escaped;
             // blocks two at a time where they match (plan.cpp deals each wave's blocks in degree order); both
             // descriptors arrive with one scalar load (plan.cpp, cn_work_desc)
             for (int w = 0; w < P.cn_work_stride; w += 2)
@@ -1329,13 +1334,13 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     break;
                 if (b1.count == 0)
                 {
-                    bad |= cn_block_ratio<MAXD, SH>(msg, b0, lane, escaped);
+                    bad |= cn_block_ratio<MAXD, SH>(msg, b0, lane, cn_esc);
                     break;
                 }
                 if (b0.count == kWaveSize && b1.count == kWaveSize)
-                    bad |= cn_pair_ratio<MAXD, SH>(msg, b0.off, b1.off, b0.degree, b1.degree, lane, escaped);
+                    bad |= cn_pair_ratio<MAXD, SH>(msg, b0.off, b1.off, b0.degree, b1.degree, lane, cn_esc);
                 else
-                    bad |= cn_block_ratio<MAXD, SH>(msg, b0, lane, escaped) | cn_block_ratio<MAXD, SH>(msg, b1, lane, escaped);
+                    bad |= cn_block_ratio<MAXD, SH>(msg, b0, lane, cn_esc) | cn_block_ratio<MAXD, SH>(msg, b1, lane, cn_esc);
             }
             const int ph = I & 1;
             int wave_vote = (__ballot(bad != 0) != 0) | ((__ballot(DM_RATIO_ESCAPED(escaped)) != 0) << 1);
@@ -1392,6 +1397,8 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                         dst[e] = msg[e]; // c2v of iteration I as lambda (sign bit: a decision); the resuming kernel takes the logarithm
                     return;
                 }
+            if constexpr (SH == 2)
+                escaped = escaped > esc6 ? escaped : esc6; // voted on after the next check-node pass, ahead of its syndrome
             // ---- VN pass, APP and hard decision: decoder.cpp:48-64 ----
             if constexpr (LLR_MODE == kLlrRegs)
             {
@@ -2187,7 +2194,7 @@ int launch_decode_impl(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, vo
     if (ratio && (min_sum || a.iterations == 0 || !a.redo_count || (a.redo_count_in && !a.ratio_separate) ||
                   (handover && (!a.redo_iter || !a.ws_handover))))
         return hipErrorInvalidValue;
-    if (a.ratio_separate && (!ratio || handover || !LDS_RESIDENT))
+    if (a.ratio_separate && (!ratio || handover || (!LDS_RESIDENT && MAXD < 6)))
         return hipErrorInvalidValue;
     if (a.redo_iter_in && !a.ws_handover)
         return hipErrorInvalidValue;
@@ -2227,6 +2234,9 @@ int launch_decode_impl(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, vo
         else if (ratio && a.ratio_separate)
             k = want_llr ? decode_kernel<false, true, true, MAXD, LLR_MODE, true, true> : decode_kernel<false, false, true, MAXD, LLR_MODE, true, true>;
     }
+    if constexpr (!LDS_RESIDENT && MAXD >= 6)
+        if (ratio && a.ratio_separate)
+            k = want_llr ? decode_kernel<false, true, false, MAXD, LLR_MODE, true, true> : decode_kernel<false, false, false, MAXD, LLR_MODE, true, true>;
     if (handover && !LDS_RESIDENT)
         return hipErrorInvalidValue; // (the memory-resident decoder runs the LLR-domain form when early termination is off)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -324,6 +324,7 @@ enum MathFn : int
     kMathCnLlr6,
     kMathCnRatio3s,     // dm_cn3_shared / dm_cn4_shared: the shared-reciprocal forms
     kMathCnRatio4s,
+    kMathCnRatio6s,     // dm_cn6_shared: degree 6, two reciprocals
     kMathCount
 };
 int math_selftest_width(int fn); // values per element in a / out (0 = unknown function)

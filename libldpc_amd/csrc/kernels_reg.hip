@@ -31,8 +31,10 @@ namespace
 
 // (the shared-reciprocal form of detmath.h belongs to the LDS-resident decoder: its range check rides on that kernel's
 // check-node-first loop; here every output is divided separately)
-template <bool MINSUM, bool RATIO, int MAXD>
-__device__ __forceinline__ void cn_regs(double (&m)[MAXD], int degree)
+// SH6: first launch of three — check nodes of degree 6 share reciprocals (detmath.h, dm_cn6_shared); their products' range
+// check joins `escaped`, voted on after the variable-node pass that follows
+template <bool MINSUM, bool RATIO, int MAXD, bool SH6>
+__device__ __forceinline__ void cn_regs(double (&m)[MAXD], int degree, uint32_t *escaped)
 {
     // wave-uniform degree: one fully unrolled recursion per width
 #define LDPC_CASE(D)                         \
@@ -41,7 +43,7 @@ __device__ __forceinline__ void cn_regs(double (&m)[MAXD], int degree)
         double v[D];                         \
         _Pragma("unroll") for (int j = 0; j < D; ++j) v[j] = m[j]; \
         if constexpr (RATIO)                 \
-            cn_ratio<D>(v);                  \
+            cn_ratio<D, false, SH6>(v, nullptr, escaped); \
         else                                 \
             cn_core<D, MINSUM>(v);           \
         _Pragma("unroll") for (int j = 0; j < D; ++j) m[j] = v[j]; \
@@ -89,10 +91,11 @@ __device__ __forceinline__ int wave_sum_i(int v)
 
 // RATIO: the likelihood-ratio form of the sum-product iteration, exactly as in kernels.hip (v2c = rho, c2v = lambda,
 // input LLRs kept as lambda; frames that leave the representable box go to a.redo_list).
-template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, bool RATIO>
+template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, bool RATIO, bool SH6 = false>
 __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, const DevRegPlan R)
 {
     static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
+    static_assert(RATIO || !SH6, "shared reciprocals belong to the ratio form");
     constexpr int kRegWaves = NT / 64;
     extern __shared__ double mb[]; // mailbox: mb_doubles doubles, then mb_doubles hard-bit bytes
     __shared__ int misc[4];
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(NT) void decode_reg_kernel(const DecodeArgs a, cons
         // ---- CN pass (decoder.cpp:25-45), entirely in registers ----
         // (a fold expression, not a loop: every m[k] must be a compile-time register row)
         [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
-            ((have[Ks] ? cn_regs<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks]) : void()), ...);
+            ((have[Ks] ? cn_regs<MINSUM, RATIO, MAXD, SH6>(m[Ks], deg[Ks], &escaped) : void()), ...);
         }(std::make_integer_sequence<int, KC>{});
 
         int par[KC];
@@ -345,12 +348,14 @@ template <int NT, int KC, int MAXD>
 int launch_reg(const DecodeArgs &a, const DevRegPlan &r, bool min_sum, void *stream)
 {
     const bool want_llr = a.llr_out != nullptr;
-    const bool ratio = a.redo_list != nullptr;
-    if (ratio && (min_sum || !a.early_term || a.iterations == 0 || !a.redo_count || a.redo_count_in))
+    const bool ratio = a.redo_list != nullptr; // (with a list coming in as well: the second launch, outputs divided separately)
+    if (ratio && (min_sum || !a.early_term || a.iterations == 0 || !a.redo_count))
         return hipErrorInvalidValue;
     void (*k)(const DecodeArgs, const DevRegPlan) = nullptr;
     if (min_sum)
         k = want_llr ? decode_reg_kernel<true, true, NT, KC, MAXD, false> : decode_reg_kernel<true, false, NT, KC, MAXD, false>;
+    else if (ratio && !a.redo_count_in && MAXD >= 6)
+        k = want_llr ? decode_reg_kernel<false, true, NT, KC, MAXD, true, MAXD >= 6> : decode_reg_kernel<false, false, NT, KC, MAXD, true, MAXD >= 6>;
     else if (ratio)
         k = want_llr ? decode_reg_kernel<false, true, NT, KC, MAXD, true> : decode_reg_kernel<false, false, NT, KC, MAXD, true>;
     else

@@ -41,10 +41,11 @@ namespace ldpc_amd
 namespace
 {
 
-// (the shared-reciprocal form of detmath.h belongs to the LDS-resident decoder: its range check rides on that kernel's
-// check-node-first loop; here every output is divided separately)
-template <bool MINSUM, bool RATIO, int MAXD>
-__device__ __forceinline__ void cn_regs2(double (&m)[MAXD], int degree)
+// SH6: the first of the three launches — check nodes of degree 6 share reciprocals (detmath.h, dm_cn6_shared); the range
+// check of their products joins `escaped`, which is voted on at the top of the NEXT pass: it counts once the frame has gone
+// on to the variable-node pass, as the rule says
+template <bool MINSUM, bool RATIO, int MAXD, bool SH6>
+__device__ __forceinline__ void cn_regs2(double (&m)[MAXD], int degree, uint32_t *escaped)
 {
     // wave-uniform degree: one fully unrolled recursion per width
 #define LDPC_CASE(D)                                                \
@@ -53,7 +54,7 @@ __device__ __forceinline__ void cn_regs2(double (&m)[MAXD], int degree)
         double v[D];                                                \
         _Pragma("unroll") for (int j = 0; j < D; ++j) v[j] = m[j];  \
         if constexpr (RATIO)                                        \
-            cn_ratio<D>(v);                                         \
+            cn_ratio<D, false, SH6>(v, nullptr, escaped);           \
         else                                                        \
             cn_core<D, MINSUM>(v);                                  \
         _Pragma("unroll") for (int j = 0; j < D; ++j) m[j] = v[j];  \
@@ -117,18 +118,21 @@ __device__ __forceinline__ Reg2VnBlock load_vn_block(const Reg2VnBlock *table, u
 // (DevReg2Plan::vn_affine): a round is straight-line code — channel terms fetched before the barrier that opens the
 // round, all its mailbox reads in flight together, the divisions of its blocks interleaved.
 template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, int NV0, int NV1, bool RATIO, bool REDO, bool UCN, bool UVN>
-__global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, const DevReg2Plan R)
+__global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a_arg, const DevReg2Plan R_arg)
 {
+    const DecodeArgs &a = a_arg;
     static_assert(NV0 % 2 == 0 && NV1 % 2 == 0, "variable-node rounds go two blocks at a time");
     static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
-    static_assert(!(RATIO && REDO), "the second pass runs the LLR-domain form");
+    // RATIO && !REDO: first launch (degree-6 check nodes share reciprocals); RATIO && REDO: second launch, over the frames the
+    // first handed back, every output divided separately; !RATIO && REDO: third launch, LLR domain, over what the second handed back
+    constexpr bool SH6 = RATIO && !REDO;
     constexpr int W = NT / 64, NV = NV0 + NV1;
-    extern __shared__ double lds[]; // R.lds_entries doubles, then two vote words
+    extern __shared__ double lds[]; // R_arg.lds_entries doubles, then two vote words
     const DevPlan &P = a.plan;
     const int nc = P.nc;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     __builtin_amdgcn_s_setprio(3); // ahead of the noise generator's waves in the SIMD's instruction arbitration (kernels.hip)
-    uint32_t *vote = reinterpret_cast<uint32_t *>(lds + R.lds_entries);
+    uint32_t *vote = reinterpret_cast<uint32_t *>(lds + R_arg.lds_entries);
     if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>((double __attribute__((address_space(3))) *)lds)) != 0)
         __builtin_trap(); // the dynamic LDS array does not start at 0: the packed addresses would be wrong
     // REDO: second pass over the frames the ratio form handed back (a.redo_list_in[0 .. *a.redo_count_in)); a small grid
@@ -142,6 +146,19 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
     }
     for (;;)
     {
+    // a launch over a list walks it in a loop: the tables' addresses are taken afresh for every frame — values loaded through
+    // them would otherwise be kept (spilled) across the whole decode of a frame for the benefit of the next one, and scratch
+    // beyond 280 bytes per lane makes every launch of the kernel allocate it anew (0.1 - 0.2 ms for a list that is almost
+    // always empty)
+    // (likewise every address derived from the thread index)
+    DevReg2Plan R = R_arg;
+    int tid = tid0;
+    if constexpr (REDO)
+    {
+        asm volatile("" : "+s"(R.edge_w), "+s"(R.cn_deg), "+s"(R.vn_blocks), "+s"(R.vn_rank));
+        asm volatile("" : "+v"(tid));
+    }
+    const int lane = tid & 63;
     const uint64_t frame = REDO ? static_cast<uint64_t>(uniform_table(a.redo_list_in)[redo_slot]) : blockIdx.x;
     double *llr = a.ws_llr + frame * nc;
     uint8_t *hard = a.ws_hb + frame * nc;
@@ -304,7 +321,10 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
                     asm volatile("" : "+s"(fr));                 // the loop would be spilled across it)
                     a.redo_list[atomicAdd(a.redo_count, 1u)] = fr;
                 }
-                return;
+                if constexpr (!REDO)
+                    return;
+                else
+                    goto next_frame;
             }
             if (I > 0 && a.early_term && !(v & 1u)) // decoder.cpp:66-72: the decisions of iteration I-1 are a codeword
             {
@@ -323,12 +343,17 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
                  if constexpr (!UCN)
                  {
                      if (deg[Ks] >= 2)
-                         cn_regs2<MINSUM, RATIO, MAXD>(m[Ks], deg[Ks]);
+                         cn_regs2<MINSUM, RATIO, MAXD, SH6>(m[Ks], deg[Ks], &escaped);
                  }
                  else if constexpr (RATIO)
-                     cn_ratio<MAXD>(m[Ks]);
+                     cn_ratio<MAXD, false, SH6>(m[Ks], nullptr, &escaped);
                  else
                      cn_core<MAXD, MINSUM>(m[Ks]);
+                 // one node after the other: the next one's inputs exist when this one's outputs do (left to itself the compiler
+                 // works on all KC nodes at once and spills: 204 bytes per lane with the shared reciprocals)
+                 if constexpr (UCN && MAXD == 6 && Ks + 1 < KC)
+                     asm volatile("" : "+v"(m[Ks][3]), "+v"(m[Ks][4]), "+v"(m[Ks][5]), "+v"(m[Ks + 1][0]), "+v"(m[Ks + 1][1]), "+v"(m[Ks + 1][2]),
+                                       "+v"(m[Ks + 1][3]), "+v"(m[Ks + 1][4]), "+v"(m[Ks + 1][5]));
              }()),
              ...);
         }(std::make_integer_sequence<int, KC>{});
@@ -531,7 +556,7 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
         o[10] = ph_entry - 0, o[11] = __builtin_amdgcn_s_memtime() - ph_entry, o[12] = I;
     }
 #endif
-    // ---- outputs ----
+    { // ---- outputs ---- (a block: the hand-back of a frame in the second launch jumps past it)
     // (the thread index afresh: offsets derived from it before the loop would be held — spilled — across the whole decode)
     int tid_out = tid;
     asm volatile("" : "+v"(tid_out));
@@ -583,6 +608,8 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
         if (tid == 0)
             a.bit_errors[frame] = vote[2];
     }
+    } // outputs
+next_frame:
     if constexpr (!REDO)
         break;
     else
@@ -595,14 +622,19 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, con
     } // frame loop (one pass unless REDO)
 }
 
+#ifndef LDPC_AMD_REG2_LIST_GRID
+#define LDPC_AMD_REG2_LIST_GRID 96
+#endif
+constexpr unsigned kReg2ListGrid = LDPC_AMD_REG2_LIST_GRID;
+
 // U: the regular code's instantiation (no switch over check-node degrees, straight-line variable-node rounds), or the
 // generic one
 template <int NT, int KC, int MAXD, int NV0, int NV1, bool U>
 int launch_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, void *stream)
 {
     const bool want_llr = a.llr_out != nullptr;
-    const bool ratio = a.redo_list != nullptr;
-    if (ratio && (min_sum || !a.early_term || a.iterations == 0 || !a.redo_count || a.redo_count_in))
+    const bool ratio = a.redo_list != nullptr; // (with a list coming in as well: the second launch)
+    if (ratio && (min_sum || !a.early_term || a.iterations == 0 || !a.redo_count))
         return hipErrorInvalidValue;
     const bool redo = a.redo_count_in != nullptr;
     if (redo && (min_sum || !a.redo_list_in))
@@ -611,6 +643,9 @@ int launch_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, void *s
     if (min_sum)
         k = want_llr ? decode_reg2_kernel<true, true, NT, KC, MAXD, NV0, NV1, false, false, U, U>
                      : decode_reg2_kernel<true, false, NT, KC, MAXD, NV0, NV1, false, false, U, U>;
+    else if (ratio && redo)
+        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true, true, U, U>
+                     : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true, true, U, U>;
     else if (ratio)
         k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true, false, U, U>
                      : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true, false, U, U>;
@@ -620,7 +655,11 @@ int launch_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, void *s
     else
         k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, false, U, U>
                      : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, false, U, U>;
-    const unsigned grid = redo ? static_cast<unsigned>(std::min<uint64_t>(a.n_frames, 512)) : static_cast<unsigned>(a.n_frames);
+    // A launch over a list: few workgroups, each walking the list.  Every workgroup needs a whole CU, and a quarter of the CUs
+    // is busy with the noise generator's long chains beside the decode (engine.cpp): a grid that wants every CU waits for
+    // those — 0.2 ms per launch for a list that is almost always empty (512 workgroups, measured) — one that fits the free
+    // CUs does not.
+    const unsigned grid = redo ? static_cast<unsigned>(std::min<uint64_t>(a.n_frames, kReg2ListGrid)) : static_cast<unsigned>(a.n_frames);
     const uint32_t lds = r.lds_entries * 8u + 16u;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));

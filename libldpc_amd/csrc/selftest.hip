@@ -34,7 +34,7 @@ __device__ void cn_shared_rows(uint64_t i, const double *a, double *out)
     for (int j = 0; j < D; ++j)
         v[j] = a[i * D + j];
     uint32_t escaped = 0;
-    cn_ratio<D, true>(v, &escaped);
+    cn_ratio<D, D != 6, D == 6>(v, &escaped, &escaped);
 #pragma unroll
     for (int j = 0; j < D; ++j)
         out[i * D + j] = DM_RATIO_ESCAPED(escaped) ? __builtin_nan("") : v[j];
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void math_selftest_kernel(int fn, uint64_t n, 
     case kMathCnLlr6: cn_llr_rows<6>(i, a, out); break;
     case kMathCnRatio3s: cn_shared_rows<3>(i, a, out); break;
     case kMathCnRatio4s: cn_shared_rows<4>(i, a, out); break;
+    case kMathCnRatio6s: cn_shared_rows<6>(i, a, out); break;
     default: break;
     }
 }
@@ -92,7 +93,7 @@ int math_selftest_width(int fn)
     case kMathCnRatio3: case kMathCnRatio3s: return 3;
     case kMathCnRatio4: case kMathCnLlr4: case kMathCnRatio4s: return 4;
     case kMathCnRatio5: return 5;
-    case kMathCnRatio6: case kMathCnLlr6: return 6;
+    case kMathCnRatio6: case kMathCnLlr6: case kMathCnRatio6s: return 6;
     case kMathCnRatio8: return 8;
     default: return fn >= 0 && fn < kMathCount ? 1 : 0;
     }

@@ -468,12 +468,23 @@ static int is_codeword(const dec_t *d)
  */
 /* shared: nodes of degree 3 and 4 take one reciprocal of the product of their denominators (detmath.h, "Shared-reciprocal
    check nodes": what the kernels run WITH early termination); returns nonzero when such a product left its range */
-static int cn_update_ratio(dec_t *d, const int *cn, int cw, int shared)
+/* shared6: nodes of degree 6 take two reciprocals for their six outputs (dm_cn6_shared: what the kernels run WITH early
+   termination for codes their LDS-resident decoder does not take); *esc6 is set when such a product left its range — the
+   caller lets that count only once the frame has gone on to the variable-node pass */
+static int cn_update_ratio(dec_t *d, const int *cn, int cw, int shared, int shared6, int *esc6)
 {
     enum { MAXD = 64 };
     double v[MAXD] = {0};
     for (int j = 0; j < cw; ++j)
         v[j] = d->v2c[cn[j]];
+    if (shared6 && cw == 6)
+    {
+        const uint32_t p_hi = dm_cn6_shared(v);
+        for (int j = 0; j < cw; ++j)
+            d->c2v[cn[j]] = v[j];
+        *esc6 |= DM_SHARED_OVERFLOW(p_hi);
+        return 0;
+    }
     if (shared && (cw == 3 || cw == 4))
     {
         const uint32_t p_hi = cw == 3 ? dm_cn3_shared(v) : dm_cn4_shared(v);
@@ -578,7 +589,7 @@ static void ref_cn_llr(int cw, const double *v, double *out) /* decoder.cpp:31-4
 
 static int math_width(int fn)
 {
-    static const int w[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 3, 4, 5, 6, 8, 4, 6, 3, 4};
+    static const int w[] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 3, 4, 5, 6, 8, 4, 6, 3, 4, 6};
     return fn >= 0 && fn < (int)(sizeof w / sizeof w[0]) ? w[fn] : 0;
 }
 
@@ -617,7 +628,8 @@ static void det_cn_ratio(int cw, const double *v, double *out)
     for (int j = 0; j < cw; ++j)
         v2c[j] = v[j], cn[j] = j;
     d.v2c = v2c, d.c2v = c2v;
-    cn_update_ratio(&d, cn, cw, 0);
+    int e6 = 0;
+    cn_update_ratio(&d, cn, cw, 0, 0, &e6);
     for (int j = 0; j < cw; ++j)
         out[j] = c2v[j];
 }
@@ -630,9 +642,10 @@ static void det_cn_shared(int cw, const double *v, double *out) /* rows whose de
     for (int j = 0; j < cw; ++j)
         v2c[j] = v[j], cn[j] = j;
     d.v2c = v2c, d.c2v = c2v;
-    const int over = cn_update_ratio(&d, cn, cw, 1);
+    int e6 = 0;
+    const int over = cn_update_ratio(&d, cn, cw, cw != 6, cw == 6, &e6);
     for (int j = 0; j < cw; ++j)
-        out[j] = over ? NAN : c2v[j];
+        out[j] = (over || e6) ? NAN : c2v[j];
 }
 
 int orc_math_det(int fn, uint64_t n, const double *a, const double *b, double *out)
@@ -677,7 +690,7 @@ int orc_math_det(int fn, uint64_t n, const double *a, const double *b, double *o
                 out[i * w + j] = c2v[j];
             break;
         }
-        case 17: case 18: det_cn_shared(w, a + i * w, out + i * w); break;
+        case 17: case 18: case 19: det_cn_shared(w, a + i * w, out + i * w); break;
         default: det_cn_ratio(w, a + i * w, out + i * w); break;
         }
     return 0;
@@ -720,13 +733,16 @@ static int dec_decode_ratio(dec_t *d, int allow_shared)
         for (int p = H->cptr[i]; p < H->cptr[i + 1]; ++p)
             d->v2c[H->cedge[p]] = v0;
     }
-    /* shared-reciprocal check nodes (detmath.h): with early termination, for codes the LDS-resident decoder takes */
+    /* shared-reciprocal check nodes (detmath.h): with early termination; degrees 3 and 4 for codes the LDS-resident decoder
+       takes, degree 6 for the others */
     const int shared = allow_shared && d->early_term && handover_applies(d->code);
+    const int shared6 = allow_shared && d->early_term && !handover_applies(d->code);
     unsigned I = 0;
     int ret = -1;
     for (;;)
     {
         /* loop pass I: CN pass I, then the checks on what VN pass I-1 left behind, then VN pass I */
+        int esc6 = 0;
         for (int i = 0; i < H->rows && !escaped; ++i)
         {
             int cw = H->rptr[i + 1] - H->rptr[i];
@@ -735,7 +751,7 @@ static int dec_decode_ratio(dec_t *d, int allow_shared)
                 escaped = 1;
                 break;
             }
-            escaped |= cn_update_ratio(d, H->redge + H->rptr[i], cw, shared);
+            escaped |= cn_update_ratio(d, H->redge + H->rptr[i], cw, shared, shared6, &esc6);
         }
         if (escaped)
             break;
@@ -755,6 +771,11 @@ static int dec_decode_ratio(dec_t *d, int allow_shared)
                 d->c2v[e] = 0.0 - dm_log(d->c2v[e]);
             free(lam);
             return dec_decode_llr_from(d, I, 1);
+        }
+        if (esc6) /* a degree-6 node's product left its range in a pass whose outputs the frame goes on to use */
+        {
+            escaped = 1;
+            break;
         }
         for (int i = 0; i < H->cols && !escaped; ++i)
         {
@@ -980,7 +1001,7 @@ static int dec_decode(dec_t *d)
            leaves its range, again from scratch with separately divided outputs; if the box is left there too, the LLR domain */
         /* (first stage: the fused form where the code's structure admits it, fused_rule.h) */
         int it = fused_applies(d->code) ? dec_decode_fused(d) : dec_decode_ratio(d, 1);
-        if (it < 0 && d->early_term && handover_applies(d->code))
+        if (it < 0 && d->early_term)
         {
             ++g_ratio_second;
             it = dec_decode_ratio(d, 0);

@@ -204,6 +204,51 @@ def ratio_stats(reset=False):
     return done.value, esc.value
 
 
+def ratio_second():
+    """Frames whose first (shared-reciprocal) attempt was given up since the last reset of ratio_stats."""
+    f = lib().orc_ratio_second
+    f.restype = ct.c_uint64
+    return int(f())
+
+
+def craft_degree6_overflow(code, rng, big=78.0, odd=True, base=2.0, flip=0.01):
+    """Input LLRs that make a degree-6 check node's shared reciprocals overflow INSIDE the box of the ratio form (detmath.h,
+    dm_cn6_shared: the product of three denominators reaches 2^897 when the node's inputs are near |L| = 156, while every
+    message and total stays below 166).  A check node B is chosen; each of its six variable nodes v gets |L_ch| = big and a
+    helper check node whose other five neighbours have |L_ch| = big too, so that after one iteration v sends 2 * big to B.
+    odd: one of the six is negative — B is unsatisfied, its messages cancel the totals, the frame stays in the box and the
+    second launch (outputs divided separately) finishes it; even: the totals double and the frame goes on to the LLR domain."""
+    rows = [code.edge_col[code.edge_row == r] for r in range(code.mc)] if not hasattr(code, "_rows") else code._rows
+    cols = [code.edge_row[code.edge_col == v] for v in range(code.nc)] if not hasattr(code, "_cols") else code._cols
+    code._rows, code._cols = rows, cols
+    llr = np.full(code.nc, base)
+    llr[rng.random(code.nc) < flip] *= -1
+    for _ in range(1000):
+        b = int(rng.integers(code.mc))
+        if len(rows[b]) != 6:
+            continue
+        vs, helpers, used, ok = list(rows[b]), [], set(rows[b]), True
+        for v in vs:
+            cand = [a for a in cols[v] if a != b and len(rows[a]) == 6 and not (set(rows[a]) - {v}) & used]
+            if not cand:
+                ok = False
+                break
+            helpers.append(cand[0])
+            used |= set(rows[cand[0]])
+        if ok:
+            break
+    else:
+        raise AssertionError("no check node of degree 6 with six disjoint helpers")
+    for i, (v, a) in enumerate(zip(vs, helpers)):
+        s = -1.0 if (odd and i == 5) else 1.0
+        others = [u for u in rows[a] if u != v]
+        llr[v] = s * big
+        llr[others] = big
+        if s < 0:
+            llr[others[0]] = -big
+    return llr
+
+
 def mt64_stream(seed, n):
     out = np.zeros(n, np.uint64)
     lib().orc_mt64_stream(seed, n, _p(out))
@@ -234,7 +279,7 @@ def ref_dump(h, g, chan, dec, iters, early, seed, x, skip, count, tmp):
 
 
 MATH_FNS = ("exp", "log", "boxplus", "ratio_div", "ratio_rho", "ratio_lambda", "e_combine", "exp_clamped", "boxplus_exp",
-            "boxplus_log", "cn_ratio3", "cn_ratio4", "cn_ratio5", "cn_ratio6", "cn_ratio8", "cn_llr4", "cn_llr6", "cn_ratio3s", "cn_ratio4s")
+            "boxplus_log", "cn_ratio3", "cn_ratio4", "cn_ratio5", "cn_ratio6", "cn_ratio8", "cn_llr4", "cn_llr6", "cn_ratio3s", "cn_ratio4s", "cn_ratio6s")
 
 
 def math_eval(fn, a, b=None, det=False):
@@ -300,10 +345,11 @@ def math_points(fn, n, seed):
         return mix([rng.uniform(0, 710, 2 * k), rng.exponential(5, 2 * k), np.abs(edge)]), None
     if fn == "boxplus_log":
         return mix([rng.uniform(0.5, 2, 3 * k), 1 + rng.normal(0, 1e-6, k), np.array([0.5, 1.0, 2.0])]), None
-    if fn in ("cn_ratio3s", "cn_ratio4s"):
-        # the shared-reciprocal forms: inputs kept where the product of the node's denominators stays below 2^960
-        # (degree 3: |L| <= 100, degree 4: |L| <= 50); beyond that the kernels hand the frame back, covered by whole decodes
-        d, lim = (3, 100.0) if fn == "cn_ratio3s" else (4, 50.0)
+    if fn in ("cn_ratio3s", "cn_ratio4s", "cn_ratio6s"):
+        # the shared-reciprocal forms: inputs kept where the product of the node's denominators stays below 2^897
+        # (degree 3: |L| <= 100, degree 4: |L| <= 50, degree 6: |L| <= 30); beyond that the kernels hand the frame back,
+        # covered by whole decodes
+        d, lim = {"cn_ratio3s": (3, 100.0), "cn_ratio4s": (4, 50.0), "cn_ratio6s": (6, 30.0)}[fn]
         L = np.concatenate([rng.uniform(-lim, lim, (n // 2, d)), rng.normal(0, 6, (n - n // 2 - 2, d)).clip(-lim, lim),
                             np.full((1, d), lim), np.full((1, d), -lim)])
         return np.exp(L), None

@@ -28,7 +28,8 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "math_
 TOL = {"exp": (2, 0.0), "log": (2, 1e-300), "boxplus": (2, 6e-16), "ratio_div": (0, 0.0), "ratio_rho": (3, 0.0),
        "ratio_lambda": (3, 0.0), "e_combine": (3, 0.0), "exp_clamped": (2, 0.0), "boxplus_exp": (2, 0.0),
        "boxplus_log": (0, 3.5e-16), "cn_ratio3": (8, 0.0), "cn_ratio4": (8, 0.0), "cn_ratio5": (8, 0.0), "cn_ratio6": (8, 0.0),
-       "cn_ratio8": (8, 0.0), "cn_llr4": (0, 0.0), "cn_llr6": (0, 0.0), "cn_ratio3s": (8, 0.0), "cn_ratio4s": (8, 0.0)}
+       "cn_ratio8": (8, 0.0), "cn_llr4": (0, 0.0), "cn_llr6": (0, 0.0), "cn_ratio3s": (8, 0.0), "cn_ratio4s": (8, 0.0),
+       "cn_ratio6s": (10, 0.0)}
 
 
 def check(fn, a, b, got, ref):

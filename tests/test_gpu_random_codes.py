@@ -249,3 +249,37 @@ def test_fused_form_on_random_codes(case, tmp_path):
             r = d.stream_decode(6, early_term=early, iterations=iters, decoding="BP_MS" if ms else "BP", want=want)
             for k in want:
                 assert np.array_equal(r[k], o[k].astype(r[k].dtype)), (name, ch, x, ms, early, k, len(want))
+
+
+@pytest.mark.parametrize("name,vn,cn,residency,form", [
+    ("registers_totals", [3] * 8192, [6] * 4096, "registers", "totals"),
+    ("registers_messages", [1] * 600 + [3] * 7200, [6] * 3700, "registers", "messages"),
+    ("memory", [3] * 16384, [6] * 8192, "memory", None),
+])
+def test_degree6_shared_reciprocals_three_launches(name, vn, cn, residency, form, tmp_path):
+    """Codes the LDS-resident decoder does not take: with early termination their degree-6 check nodes share reciprocals in
+    the first launch (detmath.h, dm_cn6_shared), frames in which a product of denominators leaves its range are decoded again
+    with separately divided outputs (second launch) and only what leaves the box there goes on to the LLR domain (third).
+    Inputs crafted so that all three happen (orc.craft_degree6_overflow), in each of the three decoders for such codes;
+    every output bit for bit against the det oracle, which counts the stages."""
+    import libldpc_amd
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    path = make_code_by_degrees(str(tmp_path / f"{name}.txt"), vn, cn, rng)
+    code = orc.Code(path)
+    d = libldpc_amd.HipDecoder(path)
+    assert d.residency == residency and (form is None or d.register_form == form), (d.residency, d.register_form)
+    kinds = ["odd", "even", "plain", "odd", "odd", "even", "plain", "odd"]
+    frames = np.stack([orc.craft_degree6_overflow(code, rng, odd=(k == "odd")) if k != "plain"
+                       else np.where(rng.random(code.nc) < 0.02, -1.5, 2.5) for k in kinds])
+    r = d.decode_batch(frames, want=("iters", "hard", "llr_out"))
+    orc.ratio_stats(reset=True)
+    for f, k in enumerate(kinds):
+        it, out, hard = code.decode(frames[f], math=orc.MATH_DET)
+        assert it == r["iters"][f], (name, f, k)
+        assert np.array_equal(hard, r["hard"][f]) and np.array_equal(out, r["llr_out"][f]), (name, f, k)
+    done, escaped = orc.ratio_stats()
+    assert orc.ratio_second() == kinds.count("odd") + kinds.count("even")  # the first launch gave all crafted frames up
+    # the third launch took the even ones (in the code with degree-1 variable nodes some odd ones too), the second finished the rest
+    assert escaped >= kinds.count("even") and done + escaped == len(kinds) and done > kinds.count("plain")
+    assert escaped == kinds.count("even") or name == "registers_messages"
+

@@ -207,3 +207,23 @@ def test_shape_fixtures_bit_exact(tmp_path):
         assert np.array_equal(r["iters"], fx[f"{key}/iters"]) and np.array_equal(r["bit_errors"], fx[f"{key}/bit_errors"]), key
         assert np.array_equal(np.packbits(r["hard"], axis=1), fx[f"{key}/hard_packed"]), key
         assert np.array_equal(r["llr_out"], fx[f"{key}/llr_out"]), key
+
+
+def test_degree6_three_stage_rule_on_the_8k_code(h8k_file):
+    """The det oracle's three stages for codes the LDS-resident decoder does not take (shared reciprocals of degree-6 check
+    nodes, separately divided outputs, LLR domain — detmath.h, dm_cn6_shared): on inputs crafted to need the second and the
+    third stage every stage's result is the reference arithmetic's (libm oracle, itself pinned by the reference's fixtures
+    above) — same iteration count and decisions, LLRs within the parity bound 1e-5 relative."""
+    code = orc.Code(h8k_file)
+    rng = np.random.default_rng(8)
+    kinds = ["odd", "even", "plain", "odd"]
+    frames = [orc.craft_degree6_overflow(code, rng, odd=(k == "odd")) if k != "plain" else np.where(rng.random(code.nc) < 0.02, -1.5, 2.5)
+              for k in kinds]
+    orc.ratio_stats(reset=True)
+    det = [code.decode(f, math=orc.MATH_DET) for f in frames]
+    done, escaped = orc.ratio_stats()
+    assert (orc.ratio_second(), done, escaped) == (3, 3, 1)
+    for f, (it, out, hard) in zip(frames, det):
+        it2, out2, hard2 = code.decode(f, math=orc.MATH_LIBM)
+        assert it == it2 and np.array_equal(hard, hard2)
+        assert np.allclose(out, out2, rtol=1e-5, atol=1e-9)

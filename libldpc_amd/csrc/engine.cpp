@@ -794,6 +794,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
         return;
     }
     bool fused_handover_used = false;
+    bool finished_in_one = false; // the launch was the totals-form register kernel's chain of all three forms (kernels_reg2_impl.hpp)
     const auto launch = [&] {
         // the first launch of sum-product with early termination, for codes the fused form takes (fused_rule.h)
         if (fused_plan_.ok && !p.min_sum && p.early_term && a.redo_list && !a.redo_count_in && !a.ratio_separate)
@@ -835,6 +836,7 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
                 // channel terms of the variable nodes, one per (block slot, thread): kernels_reg2.hip
                 a.ws_scr = static_cast<double *>(ws_scr_.reserve(8 * n * static_cast<uint64_t>(reg2_plan_.nv0 + reg2_plan_.nv1) * reg2_plan_.nt));
                 check(launch_decode_reg2(a, dev_reg2_, p.min_sum, s), "decode (register-resident, totals form)");
+                finished_in_one = a.redo_list != nullptr;
             }
             else
                 check(launch_decode_reg(a, dev_reg_, p.min_sum, s), "decode (register-resident)");
@@ -915,6 +917,8 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
             later_stages = false;
             st.items.clear(); // (delivered)
         }
+        if (finished_in_one)
+            later_stages = false; // (nothing has been delivered yet: the outputs are flushed below as after any last launch)
         if (!later_stages)
             ;
         else if (handover)

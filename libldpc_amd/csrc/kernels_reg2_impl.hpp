@@ -112,54 +112,35 @@ __device__ __forceinline__ Reg2VnBlock load_vn_block(const Reg2VnBlock *table, u
 
 // RATIO: the likelihood-ratio form of the sum-product iteration (detmath.h): c2v messages are lambda = e^-L, the
 // returned total is rho(total) = 1 / (lambda(L_ch) * prod lambda(c2v)) with the hard decision in its sign bit, the
-// owner's v2c is rho(total) * lambda(c2v_e); frames that leave the representable box go to a.redo_list.
+// owner's v2c is rho(total) * lambda(c2v_e); a frame that leaves the representable box is given up (reg2_frame returns true).
 // UCN: every check-node block of the plan has exactly MAXD edges (a regular code): no switch over the degree, a third of
 // the code.  UVN: every variable-node block is full and of degree 3 with columns, rests and totals at affine offsets
 // (DevReg2Plan::vn_affine): a round is straight-line code — channel terms fetched before the barrier that opens the
 // round, all its mailbox reads in flight together, the divisions of its blocks interleaved.
-template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, int NV0, int NV1, bool RATIO, bool REDO, bool UCN, bool UVN>
-__global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a_arg, const DevReg2Plan R_arg)
+// One frame in one form.  RATIO: the likelihood-ratio form (sum-product with early termination); SH6: its check nodes of
+// degree 6 share reciprocals (detmath.h, dm_cn6_shared: the first of the three attempts a frame may need).  Returns true when
+// the frame left the range of the form — a value outside the box of the ratio form, or a product of denominators beyond its
+// limit — and has to be decoded again from scratch by the next form; nothing of it has been delivered then.
+template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, int NV0, int NV1, bool RATIO, bool SH6, bool UCN, bool UVN>
+__device__ __forceinline__ bool reg2_frame(const DecodeArgs &a, const DevReg2Plan &R_arg, const uint64_t frame, const int wave)
 {
-    const DecodeArgs &a = a_arg;
     static_assert(NV0 % 2 == 0 && NV1 % 2 == 0, "variable-node rounds go two blocks at a time");
     static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
-    // RATIO && !REDO: first launch (degree-6 check nodes share reciprocals); RATIO && REDO: second launch, over the frames the
-    // first handed back, every output divided separately; !RATIO && REDO: third launch, LLR domain, over what the second handed back
-    constexpr bool SH6 = RATIO && !REDO;
+    static_assert(RATIO || !SH6, "shared reciprocals belong to the ratio form");
     constexpr int W = NT / 64, NV = NV0 + NV1;
     extern __shared__ double lds[]; // R_arg.lds_entries doubles, then two vote words
     const DevPlan &P = a.plan;
     const int nc = P.nc;
-    const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    __builtin_amdgcn_s_setprio(3); // ahead of the noise generator's waves in the SIMD's instruction arbitration (kernels.hip)
     uint32_t *vote = reinterpret_cast<uint32_t *>(lds + R_arg.lds_entries);
-    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>((double __attribute__((address_space(3))) *)lds)) != 0)
-        __builtin_trap(); // the dynamic LDS array does not start at 0: the packed addresses would be wrong
-    // REDO: second pass over the frames the ratio form handed back (a.redo_list_in[0 .. *a.redo_count_in)); a small grid
-    // walks the list, so that the usual case — an empty list — costs a few hundred workgroups, not one per frame
-    uint32_t redo_slot = blockIdx.x, n_redo = 0;
-    if constexpr (REDO)
-    {
-        n_redo = *uniform_table(a.redo_count_in);
-        if (redo_slot >= n_redo)
-            return;
-    }
-    for (;;)
-    {
-    // a launch over a list walks it in a loop: the tables' addresses are taken afresh for every frame — values loaded through
-    // them would otherwise be kept (spilled) across the whole decode of a frame for the benefit of the next one, and scratch
-    // beyond 280 bytes per lane makes every launch of the kernel allocate it anew (0.1 - 0.2 ms for a list that is almost
-    // always empty)
-    // (likewise every address derived from the thread index)
+    // A frame may be decoded up to three times by this workgroup, one form after the other: the tables' addresses and the
+    // thread index are taken afresh for every attempt — the compiler would otherwise form the addresses the later attempts
+    // need ahead of the first one and keep them (spilled) across it.  (The lane index from the execution mask, the wave index
+    // from the caller's scalar register: a copy of threadIdx.x kept for the later attempts is itself such a value.)
     DevReg2Plan R = R_arg;
-    int tid = tid0;
-    if constexpr (REDO)
-    {
-        asm volatile("" : "+s"(R.edge_w), "+s"(R.cn_deg), "+s"(R.vn_blocks), "+s"(R.vn_rank));
-        asm volatile("" : "+v"(tid));
-    }
-    const int lane = tid & 63;
-    const uint64_t frame = REDO ? static_cast<uint64_t>(uniform_table(a.redo_list_in)[redo_slot]) : blockIdx.x;
+    asm volatile("" : "+s"(R.edge_w), "+s"(R.cn_deg), "+s"(R.vn_blocks), "+s"(R.vn_rank));
+    int lane = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
     double *llr = a.ws_llr + frame * nc;
     uint8_t *hard = a.ws_hb + frame * nc;
     const uint8_t *cw = a.codeword ? a.codeword + frame * nc : nullptr;
@@ -315,16 +296,7 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a_arg,
                 vote[(I + 1) & 1] = 0;
             if (RATIO && (v & 2u)) // checked before the syndrome: an escaped frame's decisions mean nothing
             {
-                if (tid == 0)
-                {
-                    uint32_t fr = static_cast<uint32_t>(frame); // (taken from the scalar register here: a vector copy made before
-                    asm volatile("" : "+s"(fr));                 // the loop would be spilled across it)
-                    a.redo_list[atomicAdd(a.redo_count, 1u)] = fr;
-                }
-                if constexpr (!REDO)
-                    return;
-                else
-                    goto next_frame;
+                return true; // (uniform: every thread has read the same vote word)
             }
             if (I > 0 && a.early_term && !(v & 1u)) // decoder.cpp:66-72: the decisions of iteration I-1 are a codeword
             {
@@ -556,7 +528,7 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a_arg,
         o[10] = ph_entry - 0, o[11] = __builtin_amdgcn_s_memtime() - ph_entry, o[12] = I;
     }
 #endif
-    { // ---- outputs ---- (a block: the hand-back of a frame in the second launch jumps past it)
+    // ---- outputs ----
     // (the thread index afresh: offsets derived from it before the loop would be held — spilled — across the whole decode)
     int tid_out = tid;
     asm volatile("" : "+v"(tid_out));
@@ -608,24 +580,36 @@ __global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a_arg,
         if (tid == 0)
             a.bit_errors[frame] = vote[2];
     }
-    } // outputs
-next_frame:
-    if constexpr (!REDO)
-        break;
-    else
-    {
-        redo_slot += gridDim.x;
-        if (redo_slot >= n_redo)
-            break;
-        __syncthreads(); // the next frame re-initialises the LDS words this one may still be reading
-    }
-    } // frame loop (one pass unless REDO)
+    return false;
 }
 
-#ifndef LDPC_AMD_REG2_LIST_GRID
-#define LDPC_AMD_REG2_LIST_GRID 96
-#endif
-constexpr unsigned kReg2ListGrid = LDPC_AMD_REG2_LIST_GRID;
+// CHAIN: sum-product with early termination — the three forms one after the other, in this workgroup, until one finishes the
+// frame (detmath.h: shared reciprocals of the degree-6 check nodes; every output divided separately; the LLR domain.  The
+// LDS-resident decoder does the same in three launches over lists; here a frame handed to a later launch would be decoded
+// by one workgroup on an otherwise idle chip — the frames that do not converge at the operating point of BASELINE config 4
+// leave the box of the ratio form after a few dozen iterations, a handful per batch, and cost 0.3 ms per batch that way —
+// while inside the first launch the repeat hides among the other frames.  Which form finishes a frame is the same either way.)
+template <bool MINSUM, bool WANT_LLR, int NT, int KC, int MAXD, int NV0, int NV1, bool CHAIN, bool U>
+__global__ __launch_bounds__(NT) void decode_reg2_kernel(const DecodeArgs a, const DevReg2Plan R)
+{
+    static_assert(!(CHAIN && MINSUM), "the chain is the sum-product decoder's");
+    extern __shared__ double lds[];
+    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>((double __attribute__((address_space(3))) *)lds)) != 0)
+        __builtin_trap(); // the dynamic LDS array does not start at 0: the packed addresses would be wrong
+    __builtin_amdgcn_s_setprio(3); // ahead of the noise generator's waves in the SIMD's instruction arbitration (kernels.hip)
+    const uint64_t frame = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (CHAIN)
+    {
+        if (!reg2_frame<false, WANT_LLR, NT, KC, MAXD, NV0, NV1, true, true, U, U>(a, R, frame, wave))
+            return;
+        __syncthreads(); // the next attempt re-initialises LDS words this one may still be reading
+        if (!reg2_frame<false, WANT_LLR, NT, KC, MAXD, NV0, NV1, true, false, U, U>(a, R, frame, wave))
+            return;
+        __syncthreads();
+    }
+    reg2_frame<MINSUM, WANT_LLR, NT, KC, MAXD, NV0, NV1, false, false, U, U>(a, R, frame, wave);
+}
 
 // U: the regular code's instantiation (no switch over check-node degrees, straight-line variable-node rounds), or the
 // generic one
@@ -633,39 +617,29 @@ template <int NT, int KC, int MAXD, int NV0, int NV1, bool U>
 int launch_reg2(const DecodeArgs &a, const DevReg2Plan &r, bool min_sum, void *stream)
 {
     const bool want_llr = a.llr_out != nullptr;
-    const bool ratio = a.redo_list != nullptr; // (with a list coming in as well: the second launch)
-    if (ratio && (min_sum || !a.early_term || a.iterations == 0 || !a.redo_count))
+    // the caller's first launch of sum-product with early termination (a list to hand frames back in): the chain kernel,
+    // which hands nothing back; its later launches over those lists have nothing to do
+    const bool chain = a.redo_list != nullptr;
+    if (chain && (min_sum || !a.early_term || a.iterations == 0))
         return hipErrorInvalidValue;
-    const bool redo = a.redo_count_in != nullptr;
-    if (redo && (min_sum || !a.redo_list_in))
-        return hipErrorInvalidValue;
+    if (a.redo_count_in)
+        return min_sum ? hipErrorInvalidValue : hipSuccess;
     void (*k)(const DecodeArgs, const DevReg2Plan) = nullptr;
     if (min_sum)
-        k = want_llr ? decode_reg2_kernel<true, true, NT, KC, MAXD, NV0, NV1, false, false, U, U>
-                     : decode_reg2_kernel<true, false, NT, KC, MAXD, NV0, NV1, false, false, U, U>;
-    else if (ratio && redo)
-        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true, true, U, U>
-                     : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true, true, U, U>;
-    else if (ratio)
-        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true, false, U, U>
-                     : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true, false, U, U>;
-    else if (redo)
-        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, true, U, U>
-                     : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, true, U, U>;
+        k = want_llr ? decode_reg2_kernel<true, true, NT, KC, MAXD, NV0, NV1, false, U>
+                     : decode_reg2_kernel<true, false, NT, KC, MAXD, NV0, NV1, false, U>;
+    else if (chain)
+        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, true, U>
+                     : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, true, U>;
     else
-        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, false, U, U>
-                     : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, false, U, U>;
-    // A launch over a list: few workgroups, each walking the list.  Every workgroup needs a whole CU, and a quarter of the CUs
-    // is busy with the noise generator's long chains beside the decode (engine.cpp): a grid that wants every CU waits for
-    // those — 0.2 ms per launch for a list that is almost always empty (512 workgroups, measured) — one that fits the free
-    // CUs does not.
-    const unsigned grid = redo ? static_cast<unsigned>(std::min<uint64_t>(a.n_frames, kReg2ListGrid)) : static_cast<unsigned>(a.n_frames);
+        k = want_llr ? decode_reg2_kernel<false, true, NT, KC, MAXD, NV0, NV1, false, U>
+                     : decode_reg2_kernel<false, false, NT, KC, MAXD, NV0, NV1, false, U>;
     const uint32_t lds = r.lds_entries * 8u + 16u;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, static_cast<hipStream_t>(stream), a, r);
+    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(a.n_frames)), dim3(NT), lds, static_cast<hipStream_t>(stream), a, r);
     return hipGetLastError();
 }
 

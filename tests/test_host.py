@@ -272,10 +272,13 @@ def test_headline_kernel_register_budget():
     assert r["VGPRs"] <= 96 and r["ScratchSize [bytes/lane]"] == 0 and r["Occupancy [waves/SIMD]"] >= 5, r
     r = fused[[k for k in fused if "decode_fused_ms_kernelILb0ELi4ELi1E" in k][0]]
     assert r["VGPRs"] <= 80 and r["ScratchSize [bytes/lane]"] == 0, r
-    # the register-resident kernel of the n = 8192 code with early termination (config 4): no scratch either
+    # the register-resident kernel of the n = 8192 code with early termination (config 4): the chain of the three forms in
+    # one kernel (kernels_reg2_impl.hpp).  Its scratch belongs to the third form (LLR domain) and to the exits; the loop of the
+    # first form holds no scratch instruction (profiles/r4_isa_budget.md shows how to look).  Far below the 280 bytes per
+    # lane beyond which the runtime allocates scratch anew at every launch.
     reg2 = build.kernel_resources("kernels_reg2u.hip")
-    r = reg2[[k for k in reg2 if "decode_reg2_kernelILb0ELb0ELi1024ELi4ELi6ELi4ELi4ELb1ELb0ELb1ELb1E" in k][0]]
-    assert r["VGPRs"] <= 128 and r["ScratchSize [bytes/lane]"] == 0, r
+    r = reg2[[k for k in reg2 if "decode_reg2_kernelILb0ELb0ELi1024ELi4ELi6ELi4ELi4ELb1ELb1E" in k][0]]
+    assert r["VGPRs"] <= 128 and r["ScratchSize [bytes/lane]"] <= 96, r
     # decode_kernel_w5<MINSUM=false, WANT_LLR=false, LDS_RESIDENT=true, MAXD=4, LLR_MODE=kLlrRegs, RATIO=true>
     key = [k for k in res if "decode_kernel_w5ILb0ELb0ELb1ELi4ELi2ELb1E" in k]
     assert len(key) == 1, key

@@ -96,7 +96,7 @@ def pmc_passes(cfg, batch, steps=2, warmup=1, passes=("sq", "mix", "fetch", "wri
                 d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             kernels = {}
             for (k, _), d in per.items():
-                if "decode" in k or "bec_kernel" in k:
+                if "decode" in k or "bec_kernel" in k or "bec_sliced_kernel" in k:
                     kernels.setdefault(k, []).append(d)
             if not kernels:
                 return {"error": "no decode kernel in the counter output"}

@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libldpc.so")
 CLI = os.path.join(PKG, "ldpcsim")
 
-LIB_SOURCES = ["kernels.hip", "kernels_reg.hip", "kernels_reg2.hip", "kernels_reg2u.hip", "kernels_fast.hip", "kernels_layered.hip", "kernels_fused.hip", "rng_kernels.hip", "selftest.hip", "engine.cpp", "comm.cpp", "api.cpp", "sim.cpp", "code.cpp", "plan.cpp", "mt64.cpp", "mtstates.cpp"]
+LIB_SOURCES = ["kernels.hip", "kernels_reg.hip", "kernels_reg2.hip", "kernels_reg2u.hip", "kernels_fast.hip", "kernels_layered.hip", "kernels_fused.hip", "kernels_bec.hip", "rng_kernels.hip", "selftest.hip", "engine.cpp", "comm.cpp", "api.cpp", "sim.cpp", "code.cpp", "plan.cpp", "mt64.cpp", "mtstates.cpp"]
 CLI_SOURCES = ["ldpcsim_main.cpp"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every fused multiply-add is written explicitly (detmath.h); results must not

@@ -269,7 +269,7 @@ void MtDevice::apply(const std::vector<StateOp> &ops, uint64_t *table, void *str
                   "state copy");
             break;
         case StateOp::kJump:
-            check(launch_mt_jump(table, op.mod, op.src, op.dst, device_poly(op.stride, stream), op.n, jump_pack_, s), "mt_jump");
+            check(launch_mt_jump(table, op.mod, op.src, op.dst, device_poly(op.stride, stream), op.n, jump_pack_, jump_groups_, s), "mt_jump");
             jump_tasks_ += op.n;
             break;
         }
@@ -1189,6 +1189,9 @@ void Engine::stream_begin(int channel, uint64_t seed, double x, bool fresh)
     if (channel != kAwgn && channel != kBsc && channel != kBec)
         throw std::runtime_error("No channel selected.");
     chan_ = channel;
+    // jump-ahead in four thread groups where its latency counts: the erasure channel (its bit-sliced decoder leaves the noise
+    // chain on the critical path) and beside the register-resident decoders (rng_kernels.hip, mt_jump_kernel)
+    noise_.st.set_jump_groups(channel == kBec || reg_plan_.ok ? 4 : 1);
     x_ = x;
     frame_pos_ = 0;
     raw_next_ = 0;

@@ -113,6 +113,7 @@ class MtDevice
     void prefetch_strided();
     uint64_t jump_tasks() const { return jump_tasks_; } // jump-ahead tasks launched so far (tools/shard_probe.py)
     void set_jump_pack(int tasks_per_workgroup) { jump_pack_ = tasks_per_workgroup; } // kernels.hpp launch_mt_jump
+    void set_jump_groups(int groups) { jump_groups_ = groups; }
 
   private:
     void apply(const std::vector<StateOp> &ops, uint64_t *table, void *stream);
@@ -127,6 +128,7 @@ class MtDevice
     std::vector<std::pair<uint64_t, void *>> polys_; // (stride in chunks, device copy)
     uint64_t jump_tasks_ = 0;
     int jump_pack_ = 1;
+    int jump_groups_ = 1;
     bool ring_polys_ready_ = false;
     // look-ahead launches in flight on jump_stream_: the ring rows of chunks [hi_before, hi_after) are valid after `event`
     struct Ahead

@@ -2328,6 +2328,9 @@ int launch_bec(const BecArgs &a, void *stream)
 {
     if (a.n_frames == 0)
         return hipSuccess;
+    // codes whose bit-sliced state fits LDS: 64 frames per workgroup (kernels_bec.hip); LDPC_AMD_NO_BEC_SLICED: experiments
+    if (!a.ws && bec_sliced_fits(a.plan) && !std::getenv("LDPC_AMD_NO_BEC_SLICED"))
+        return launch_bec_sliced(a, stream);
     const uint32_t lds = a.ws ? 16u : bec_state_bytes(a.plan.nnz, a.plan.nc);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bec_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

@@ -173,6 +173,10 @@ struct BecArgs
     uint8_t *ws;         // per-frame state in device memory (codes whose nnz + 2 nc bytes exceed LDS), else nullptr
 };
 
+// erasure decoder, 64 frames per workgroup (kernels_bec.hip); launch_bec (kernels.hip) takes it when the code fits
+bool bec_sliced_fits(const DevPlan &p);
+int launch_bec_sliced(const BecArgs &a, void *stream);
+
 // All launchers enqueue on `stream` (hipStream_t passed as void*) and return a hipError_t as int.
 // LDS-resident decoder; llr_mode: 0 input LLRs in LDS, 1 in device memory (a.ws_llr), 2 in registers
 // (needs plan.vn_work_stride <= 8 and no isolated variable node)
@@ -211,9 +215,10 @@ int launch_mt_generate(const uint64_t *ring, uint32_t ring_rows, uint32_t first_
 // Jump: row (dst_first + t) % ring_rows = row (src_first + t) % ring_rows advanced by the polynomial `poly` (19937
 // coefficient bits, kJumpPolyWords words: 312 + zero padding), t < n_tasks.  A task reads its source row before it writes,
 // so src_first == dst_first (in place) is allowed; otherwise the two row ranges must not overlap.
-// pack: tasks per workgroup (1, or 3 beside decode kernels that own a whole CU).
+// groups: 4 = one task per workgroup, its taps shared by four thread groups (a short chain: where the jump is on the critical
+// path or holds a CU a decoder wants); else one group, `pack` tasks per workgroup (1 or 3) — rng_kernels.hip says which where.
 int launch_mt_jump(uint64_t *ring, uint32_t ring_rows, uint32_t src_first, uint32_t dst_first, const uint64_t *poly,
-                   uint32_t n_tasks, int pack, void *stream);
+                   uint32_t n_tasks, int pack, int groups, void *stream);
 constexpr uint32_t kJumpPolyWords = 320;
 
 // The AWGN noise generator: chunks of the raw stream -> the normal variates the reference's normal_distribution would

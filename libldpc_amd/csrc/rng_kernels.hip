@@ -21,6 +21,8 @@
 // The arithmetic of the acceptance test is device_math.hpp::polar_trial.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_math.hpp"
 #include "kernels.hpp"
 
@@ -147,29 +149,43 @@ __global__ __launch_bounds__(kGenThreads *kGenChunks) void mt_generate_kernel(co
 // consecutive words.  Wave 0 then regenerates the next block and the ring advances.  The taps of a stage
 // are taken eight at a time: eight independent LDS reads in flight, then eight XORs predicated on
 // wave-uniform coefficient bits.
-constexpr int kJumpThreads = 192;    // per task: thread i < 156 owns output words 2i and 2i+1; wave 0 also runs the generator
+constexpr int kJumpThreads = 192;    // per thread group: thread i < 156 owns output words 2i and 2i+1
 constexpr int kJumpStages = 64;      // 64 * 312 = 19968 >= 19937 taps
 constexpr int kPolyWords = 320;      // 312 coefficient words + zero padding read by the last stage
 
+// kGroups thread groups per task share a stage's taps (group q takes the eights q, q + kGroups, ...) and XOR their partial
+// windows together at the end: the task is a chain of 64 stages whose length is one group's share of the taps, and a batch
+// has only a couple of hundred tasks — the chain's latency, not the chip's throughput, is what a jump costs (round 4: one
+// group of 192 threads took 0.7 ms per launch, which bounded the erasure channel's whole step once its decoder had become
+// bit-sliced; four groups with branches take a fraction of that).  The eight coefficient bits of a step are wave-uniform:
+// with kBranch the XORs of a zero coefficient are BRANCHED over (an empty asm in the body keeps the compiler from turning the
+// branch back into sixteen selects per step, of which half do nothing: the polynomial's density is one half).
+// Which form runs where is a measurement (same box, A/B): the short chain wins where the jump is on the critical path (the
+// erasure channel: 0.70 -> 0.39 ms of noise chain per step) and beside the register-resident decoders (its workgroup holds
+// a CU a tenth as long: config 4 4.26 -> 4.20 ms); beside the LDS-resident sum-product decoders, whose issue slots it
+// shares, the slow trickle of ONE group of masked XORs disturbs least (headline step 2.71 ms; one group with branches 2.73,
+// four groups 2.75) and stays.
 // kPack tasks per workgroup (their waves share nothing but the barriers): beside a decode kernel whose workgroup owns a
-// whole CU, every resident jump workgroup keeps a frame out for as long as it runs — three tasks in one workgroup hold
-// a third of the CUs for the same time.
-template <int kPack>
-__global__ __launch_bounds__(kJumpThreads *kPack) void mt_jump_kernel(uint64_t *table, uint32_t ring_rows, uint32_t src_first,
-                                                                      uint32_t dst_first, const uint64_t *poly, uint32_t n_tasks)
+// whole CU, every resident jump workgroup keeps a frame out for as long as it runs.
+template <int kPack, int kGroups, bool kBranch>
+__global__ __launch_bounds__(kJumpThreads *kGroups *kPack) void mt_jump_kernel(uint64_t *table, uint32_t ring_rows, uint32_t src_first,
+                                                                               uint32_t dst_first, const uint64_t *poly, uint32_t n_tasks)
 {
+    constexpr int kTask = kJumpThreads * kGroups; // threads per task
     __shared__ uint64_t xs[kPack][kMtN];                                  // generator state = newest block
     __shared__ __attribute__((aligned(16))) uint64_t rings[kPack][2 * kMtN];
     __shared__ uint64_t g[kPolyWords];
-    const int tid = threadIdx.x % kJumpThreads, sub = threadIdx.x / kJumpThreads;
+    __shared__ uint64_t part[kPack][kGroups > 1 ? kGroups - 1 : 1][kMtN]; // partial windows of groups 1..
+    const int tid = threadIdx.x % kTask, sub = threadIdx.x / kTask;
+    const int q = __builtin_amdgcn_readfirstlane(tid / kJumpThreads), t = tid % kJumpThreads; // (192 = three whole waves)
     const uint32_t task = blockIdx.x * kPack + sub;
     const bool live = task < n_tasks;
     uint64_t *x = xs[sub], *ring = rings[sub];
     const uint64_t *src = table + static_cast<size_t>(ring_index(ring_rows, src_first, live ? task : 0)) * kMtN;
     uint64_t *dst = table + static_cast<size_t>(ring_index(ring_rows, dst_first, live ? task : 0)) * kMtN;
-    for (int k = threadIdx.x; k < kPolyWords; k += kJumpThreads * kPack)
+    for (int k = threadIdx.x; k < kPolyWords; k += kTask * kPack)
         g[k] = poly[k];
-    for (int k = tid; k < kMtN; k += kJumpThreads)
+    for (int k = tid; k < kMtN; k += kTask)
     {
         const uint64_t v = src[k];
         x[k] = v;
@@ -179,18 +195,18 @@ __global__ __launch_bounds__(kJumpThreads *kPack) void mt_jump_kernel(uint64_t *
     if (tid < 64)
         mt_regenerate(x, tid);
     __syncthreads();
-    for (int k = tid; k < kMtN; k += kJumpThreads)
+    for (int k = tid; k < kMtN; k += kTask)
         ring[kMtN + k] = x[k];
     __syncthreads();
 
     uint64_t acc0 = 0, acc1 = 0;
     for (int b = 0; b < kJumpStages; ++b)
     {
-        if (tid < kMtN / 2)
+        if (t < kMtN / 2)
         {
             const int k0 = b * kMtN;
-            const uint64_t *rp = ring + 2 * tid; // 16-byte aligned: the eight taps' words for both outputs are nine consecutive words
-            for (int kk = 0; kk < kMtN; kk += 8)
+            const uint64_t *rp = ring + 2 * t; // 16-byte aligned: the eight taps' words for both outputs are nine consecutive words
+            for (int kk = 8 * q; kk < kMtN; kk += 8 * kGroups)
             {
                 // eight coefficient bits starting at k0 + kk (wave-uniform)
                 const int k = k0 + kk;
@@ -204,29 +220,47 @@ __global__ __launch_bounds__(kJumpThreads *kPack) void mt_jump_kernel(uint64_t *
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                 {
-                    const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(rp + kk + 2 * j);
-                    v[2 * j] = q.x, v[2 * j + 1] = q.y;
+                    const ulonglong2 u = *reinterpret_cast<const ulonglong2 *>(rp + kk + 2 * j);
+                    v[2 * j] = u.x, v[2 * j + 1] = u.y;
                 }
                 v[8] = rp[kk + 8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (bits >> j & 1)
+                    {
                         acc0 ^= v[j], acc1 ^= v[j + 1];
+                        if constexpr (kBranch)
+                            asm volatile(""); // (a real branch: see above)
+                    }
             }
         }
         __syncthreads();
         // advance: block b+1 becomes the low half, wave 0 produces block b+2
         if (tid < 64)
             mt_regenerate(x, tid);
-        uint64_t up0 = ring[kMtN + tid], up1 = tid + kJumpThreads < kMtN ? ring[kMtN + tid + kJumpThreads] : 0;
+        uint64_t up[(kMtN + kTask - 1) / kTask];
+#pragma unroll
+        for (int r = 0; r < (kMtN + kTask - 1) / kTask; ++r)
+            up[r] = tid + r * kTask < kMtN ? ring[kMtN + tid + r * kTask] : 0;
         __syncthreads();
-        ring[tid] = up0, ring[kMtN + tid] = x[tid];
-        if (tid + kJumpThreads < kMtN)
-            ring[tid + kJumpThreads] = up1, ring[kMtN + tid + kJumpThreads] = x[tid + kJumpThreads];
+#pragma unroll
+        for (int r = 0; r < (kMtN + kTask - 1) / kTask; ++r)
+            if (tid + r * kTask < kMtN)
+                ring[tid + r * kTask] = up[r], ring[kMtN + tid + r * kTask] = x[tid + r * kTask];
         __syncthreads();
     }
-    if (live && tid < kMtN / 2) // (the task's own source row was read into LDS at the start: in place is fine)
-        dst[2 * tid] = acc0, dst[2 * tid + 1] = acc1;
+    if constexpr (kGroups > 1)
+    {
+        if (q > 0 && t < kMtN / 2)
+            part[sub][q - 1][2 * t] = acc0, part[sub][q - 1][2 * t + 1] = acc1;
+        __syncthreads();
+        if (q == 0 && t < kMtN / 2)
+#pragma unroll
+            for (int r = 0; r < kGroups - 1; ++r)
+                acc0 ^= part[sub][r][2 * t], acc1 ^= part[sub][r][2 * t + 1];
+    }
+    if (live && q == 0 && t < kMtN / 2) // (the task's own source row was read into LDS at the start: in place is fine)
+        dst[2 * t] = acc0, dst[2 * t + 1] = acc1;
 }
 
 // ---- AWGN: raw chunk -> slab of normals -------------------------------------------------------------------------
@@ -446,17 +480,25 @@ int launch_mt_generate(const uint64_t *ring, uint32_t ring_rows, uint32_t first_
 }
 
 int launch_mt_jump(uint64_t *ring, uint32_t ring_rows, uint32_t src_first, uint32_t dst_first, const uint64_t *poly,
-                   uint32_t n_tasks, int pack, void *stream)
+                   uint32_t n_tasks, int pack, int groups, void *stream)
 {
     if (n_tasks == 0)
         return hipSuccess;
     if (src_first >= ring_rows || dst_first >= ring_rows || n_tasks > ring_rows)
         return hipErrorInvalidValue;
-    if (pack >= 3)
-        hipLaunchKernelGGL(mt_jump_kernel<3>, dim3((n_tasks + 2) / 3), dim3(kJumpThreads * 3), 0, static_cast<hipStream_t>(stream), ring,
+    // groups = 4: one task per workgroup in four groups with branches (a short chain); else the one-group kernel with masked
+    // XORs, `pack` tasks to a workgroup (LDPC_AMD_JUMP_GROUPS: experiments)
+    static const int groups_env = std::getenv("LDPC_AMD_JUMP_GROUPS") ? std::atoi(std::getenv("LDPC_AMD_JUMP_GROUPS")) : 0;
+    if (groups_env)
+        groups = groups_env;
+    if (groups >= 4)
+        hipLaunchKernelGGL((mt_jump_kernel<1, 4, true>), dim3(n_tasks), dim3(kJumpThreads * 4), 0, static_cast<hipStream_t>(stream), ring, ring_rows,
+                           src_first, dst_first, poly, n_tasks);
+    else if (pack >= 3)
+        hipLaunchKernelGGL((mt_jump_kernel<3, 1, false>), dim3((n_tasks + 2) / 3), dim3(kJumpThreads * 3), 0, static_cast<hipStream_t>(stream), ring,
                            ring_rows, src_first, dst_first, poly, n_tasks);
     else
-        hipLaunchKernelGGL(mt_jump_kernel<1>, dim3(n_tasks), dim3(kJumpThreads), 0, static_cast<hipStream_t>(stream), ring, ring_rows,
+        hipLaunchKernelGGL((mt_jump_kernel<1, 1, false>), dim3(n_tasks), dim3(kJumpThreads), 0, static_cast<hipStream_t>(stream), ring, ring_rows,
                            src_first, dst_first, poly, n_tasks);
     return hipGetLastError();
 }

@@ -59,7 +59,7 @@ for d in sorted(glob.glob(os.path.join(src, "cfg*"))):
         for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
-                if "ldpc_amd" not in k or not ("decode" in k or "bec_kernel" in k):
+                if "ldpc_amd" not in k or not ("decode" in k or "bec_kernel" in k or "bec_sliced_kernel" in k):
                     continue
                 e = per.setdefault(short(k), {}).setdefault((sub, r["Dispatch_Id"]), {"ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
                 e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])

@@ -236,6 +236,19 @@ const uint64_t *MtDevice::device_poly(uint64_t stride, void *stream)
     for (auto &p : polys_)
         if (p.first == stride)
             return static_cast<const uint64_t *>(p.second);
+    // bounded: beyond 64 device copies the older half goes, except the ring's powers of two (launches that read them may be
+    // in flight: the device is drained first — once per 32 new step geometries of a simulation, if ever)
+    if (polys_.size() >= 64)
+    {
+        check(hipDeviceSynchronize(), "sync before trimming the polynomial cache");
+        std::vector<std::pair<uint64_t, void *>> keep;
+        for (size_t i = 0; i < polys_.size(); ++i)
+            if (i >= polys_.size() / 2 || (polys_[i].first & (polys_[i].first - 1)) == 0)
+                keep.push_back(polys_[i]);
+            else
+                (void)hipFree(polys_[i].second);
+        polys_.swap(keep);
+    }
     const Gf2Poly &g = chunk_jump_poly(chunk_blocks_, stride);
     std::vector<uint64_t> padded(kJumpPolyWords, 0);
     std::copy(g.begin(), g.begin() + kMtWords, padded.begin());

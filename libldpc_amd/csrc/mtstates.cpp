@@ -2,6 +2,7 @@
 #include "mtstates.hpp"
 
 #include <algorithm>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -39,6 +40,12 @@ const Gf2Poly &chunk_jump_poly(uint32_t chunk_blocks, uint64_t n_chunks)
         }
         return cache.at(std::make_pair(chunk_blocks, uint64_t(1) << m));
     };
+    // bounded: the powers of two (at most 64 per chunk size, what everything else is built from) stay; the products — one
+    // per distinct step geometry a simulation ever used, 2.5 KB each — go when there are too many (callers copy what they get
+    // before they ask again)
+    if (cache.size() >= 256)
+        for (auto e = cache.begin(); e != cache.end();)
+            e = (e->first.second & (e->first.second - 1)) ? cache.erase(e) : std::next(e);
     Gf2Poly r;
     for (unsigned m = 0; m < 64; ++m)
         if (n_chunks >> m & 1)

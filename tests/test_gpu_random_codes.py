@@ -283,3 +283,32 @@ def test_degree6_shared_reciprocals_three_launches(name, vn, cn, residency, form
     assert escaped >= kinds.count("even") and done + escaped == len(kinds) and done > kinds.count("plain")
     assert escaped == kinds.count("even") or name == "registers_messages"
 
+
+
+@pytest.mark.parametrize("compat", [False, True], ids=["defined", "reference_compatible"])
+def test_bit_sliced_erasure_decoder_shapes(compat, tmp_path):
+    """The bit-sliced erasure decoder (kernels_bec.hip: 32 frames per workgroup) where its special paths meet: variable nodes
+    of degree 9, 11 and 20 in blocks that are not multiples of sixteen nodes (four lanes per node, partly filled units),
+    degree-1 and degree-2 nodes (the leaf rule in both modes, the swap), check nodes of degree 3..8 (inputs in registers) and
+    12 (the two-sweep loop), batches that end inside a group of 32 frames (1, 31, 33, 100) and frames that finish at very
+    different passes (the activity mask), with and without early termination: every output `==` the oracle."""
+    import libldpc_amd
+    rng = np.random.default_rng(5 + compat)
+    vn = [1] * 70 + [2] * 301 + [3] * 200 + [9] * 37 + [11] * 20 + [20] * 9
+    edges = sum(vn)
+    cn = [12] * 20 + [8] * 30 + [5] * 40 + [4] * 100 + [3] * ((edges - 12 * 20 - 8 * 30 - 5 * 40 - 4 * 100) // 3)
+    cn[-1] += edges - sum(cn)
+    path = make_code_by_degrees(str(tmp_path / "becshapes.txt"), vn, cn, rng)
+    code = orc.Code(path)
+    d = libldpc_amd.HipDecoder(path)
+    d.set_bec_compat(compat)
+    for x, early, iters, n, skip in ((0.35, True, 50, 100, 0), (0.45, True, 30, 33, 3), (0.25, False, 7, 31, 1), (0.5, True, 50, 1, 40)):
+        d.stream_begin("BEC", 9, x)
+        if skip:
+            d.stream_skip(skip)
+        r = d.stream_decode(n, early_term=early, iterations=iters, want=OUT)
+        o = code.run_frames("BEC", x, seed=9, skip=skip, count=n, early_term=early, iters=iters, bec_compat=compat)
+        for k in OUT:
+            assert np.array_equal(r[k], o[k].astype(r[k].dtype)), (x, n, k)
+        if n >= 31 and early:
+            assert r["iters"].max() - r["iters"].min() >= 3  # the frames of a group really finish apart

@@ -117,6 +117,6 @@ for cfg, p in pmc.items():
 fm = os.path.join(src, "fast_mode_report.jsonl")
 if os.path.exists(fm):
     shutil.copy(fm, os.path.join(out, f"{tag}_fast_modes.jsonl"))
-for name in ("shard_cost_cfg2.jsonl", "shard_cost_cfg4.jsonl"):
+for name in ("shard_cost_cfg2.jsonl", "shard_cost_cfg4.jsonl", "shard_cost_cfg2_gen.jsonl"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(out, f"{tag}_{name}"))

@@ -310,5 +310,5 @@ def test_bit_sliced_erasure_decoder_shapes(compat, tmp_path):
         o = code.run_frames("BEC", x, seed=9, skip=skip, count=n, early_term=early, iters=iters, bec_compat=compat)
         for k in OUT:
             assert np.array_equal(r[k], o[k].astype(r[k].dtype)), (x, n, k)
-        if n >= 31 and early:
+        if n == 100:
             assert r["iters"].max() - r["iters"].min() >= 3  # the frames of a group really finish apart

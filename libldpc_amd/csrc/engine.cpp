@@ -948,14 +948,26 @@ void Engine::run_decode(DecodeArgs &a, const DecParams &p, const BatchOut &out, 
             // from scratch with every output divided separately — the ratio form still, a twentieth of a millisecond for a
             // few dozen frames — and only what leaves the box there goes on to the LLR domain.  (A lone frame takes 0.3 ms
             // in the LLR domain, and the launches of a batch run one after the other.)
-            uint32_t *redo2 = static_cast<uint32_t *>(redo2_.reserve(4 * (n + 1)));
-            check(hipMemsetAsync(redo2, 0, 4, s), "redo count");
-            a.redo_count = redo2, a.redo_list = redo2 + 1;
-            a.ratio_separate = 1;
-            launch();
-            a.ratio_separate = 0;
-            a.redo_count = nullptr, a.redo_list = nullptr;
-            a.redo_count_in = redo2, a.redo_list_in = redo2 + 1;
+            if (plan_.lds_ok)
+            {
+                // LDS-resident: ONE more launch, over the list — separately divided outputs and, for what leaves the box there,
+                // the LLR domain, frame by frame in the same workgroup (kernels.hip, decode_kernel_list)
+                a.ratio_separate = 1;
+                launch();
+                a.ratio_separate = 0;
+                later_stages = false;
+            }
+            else
+            {
+                uint32_t *redo2 = static_cast<uint32_t *>(redo2_.reserve(4 * (n + 1)));
+                check(hipMemsetAsync(redo2, 0, 4, s), "redo count");
+                a.redo_count = redo2, a.redo_list = redo2 + 1;
+                a.ratio_separate = 1;
+                launch();
+                a.ratio_separate = 0;
+                a.redo_count = nullptr, a.redo_list = nullptr;
+                a.redo_count_in = redo2, a.redo_list_in = redo2 + 1;
+            }
         }
     }
     if (later_stages)

@@ -1002,9 +1002,11 @@ constexpr int kMaxVnBlocksInRegs = 8;
 // VNB (kLlrRegs) = VN blocks per wave the instantiation provides registers for: every one of them costs three registers
 // (LLR, packed slot indices) whether the code has that many blocks or not, so the kernels pinned at five waves per SIMD
 // are compiled for the five blocks per wave of an n = 1024 code and codes with more take the general instantiation.
+// CHAIN (decode_kernel_list): the frame is entry `slot` of a.redo_list_in (the caller has checked the count); a frame that leaves
+// the ratio form's range is not appended to a list: the function returns true and the caller goes on to the next form.
 template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO, bool HANDOVER = false, bool SEPARATE = false,
-          int VNB = kMaxVnBlocksInRegs>
-__device__ __forceinline__ void decode_body(const DecodeArgs &a)
+          int VNB = kMaxVnBlocksInRegs, bool CHAIN = false>
+__device__ __forceinline__ bool decode_body(const DecodeArgs &a, const uint32_t slot)
 {
     static_assert(VNB >= 1 && VNB <= kMaxVnBlocksInRegs, "register-held VN blocks");
     static_assert(!(RATIO && MINSUM), "the ratio form is a sum-product form");
@@ -1014,15 +1016,16 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
     __shared__ int votes[2][kDecodeWaves];
     const DevPlan &P = a.plan;
     const int nnz = P.nnz, nc = P.nc;
-    uint64_t frame = blockIdx.x;
+    uint64_t frame = slot;
     uint32_t resume_at = 0xFFFFFFFFu; // LLR-domain second pass: iteration a handed-over frame resumes at (else: from scratch)
     if (a.redo_count_in) // second pass: only the frames the ratio form handed back
     {
-        if (blockIdx.x >= *uniform_table(a.redo_count_in))
-            return;
-        frame = uniform_table(a.redo_list_in)[blockIdx.x];
+        if constexpr (!CHAIN)
+            if (slot >= *uniform_table(a.redo_count_in))
+                return false;
+        frame = uniform_table(a.redo_list_in)[slot];
         if (a.redo_iter_in)
-            resume_at = uniform_table(a.redo_iter_in)[blockIdx.x];
+            resume_at = uniform_table(a.redo_iter_in)[slot];
     }
     [[maybe_unused]] const bool resuming = !RATIO && resume_at != 0xFFFFFFFFu;
     double *msg, *llr;
@@ -1365,6 +1368,8 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
 #endif
             if (any & 2) // checked before the syndrome: an escaped frame's hard decisions mean nothing
             {
+                if constexpr (CHAIN)
+                    return true; // (uniform: every thread has read the same votes)
                 if (tid == 0)
                 {
                     const uint32_t pos = atomicAdd(a.redo_count, 1u);
@@ -1372,7 +1377,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     if constexpr (HANDOVER)
                         a.redo_iter[pos] = 0xFFFFFFFFu; // from scratch
                 }
-                return;
+                return false;
             }
             if (I > 0 && a.early_term && !(any & 1)) // decoder.cpp:66-72 after VN pass I-1
             {
@@ -1395,7 +1400,7 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
                     double *dst = a.ws_handover + static_cast<uint64_t>(static_cast<uint32_t>(misc[1])) * nnz;
                     for (int e = tid; e < nnz; e += kThreads)
                         dst[e] = msg[e]; // c2v of iteration I as lambda (sign bit: a decision); the resuming kernel takes the logarithm
-                    return;
+                    return false;
                 }
             if constexpr (SH == 2)
                 escaped = escaped > esc6 ? escaped : esc6; // voted on after the next check-node pass, ahead of its syndrome
@@ -1724,12 +1729,32 @@ __device__ __forceinline__ void decode_body(const DecodeArgs &a)
         if (a.phase_trace && frame >= 30000 && frame < 32048 && lane == 0)
             a.phase_trace[((frame - 30000) * 4 + wave) * 8 + 7] = __builtin_amdgcn_s_memtime();
 #endif
+    return false;
 }
 
 template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO, bool SEPARATE = false>
 __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 {
-    decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO, false, SEPARATE>(a);
+    decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO, false, SEPARATE>(a, blockIdx.x);
+}
+
+// LDS-resident decoder, sum-product with early termination: the frames the first launch handed back (a.redo_list_in), each
+// by the ratio form with separately divided outputs and — only if it leaves the box there too — by the LLR-domain form, in
+// this workgroup: one launch where there were two, and a small grid that WALKS the list where every frame of the batch had a
+// workgroup that looked whether it was meant (16 us per launch of 65 536 workgroups, for a list that holds a frame or none).
+template <bool WANT_LLR, int MAXD, int LLR_MODE>
+__global__ __launch_bounds__(kThreads) void decode_kernel_list(const DecodeArgs a)
+{
+    const uint32_t n = *uniform_table(a.redo_count_in);
+    for (uint32_t slot = blockIdx.x; slot < n; slot += gridDim.x)
+    {
+        if (decode_body<false, WANT_LLR, true, MAXD, LLR_MODE, true, false, true, kMaxVnBlocksInRegs, true>(a, slot))
+        {
+            __syncthreads(); // the next form re-initialises LDS words this one may still be reading
+            decode_body<false, WANT_LLR, true, MAXD, LLR_MODE, false, false, false, kMaxVnBlocksInRegs, true>(a, slot);
+        }
+        __syncthreads();
+    }
 }
 
 #ifndef LDPC_AMD_HANDOVER_WAVES
@@ -1738,7 +1763,7 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(const DecodeArgs a)
 template <bool WANT_LLR, int MAXD, int LLR_MODE, int VNB = kMaxVnBlocksInRegs>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(LDPC_AMD_HANDOVER_WAVES, 5))) void decode_kernel_handover(const DecodeArgs a)
 {
-    decode_body<false, WANT_LLR, true, MAXD, LLR_MODE, true, true, false, VNB>(a);
+    decode_body<false, WANT_LLR, true, MAXD, LLR_MODE, true, true, false, VNB>(a, blockIdx.x);
 }
 
 // The same body compiled for five waves per SIMD (at most 96 VGPRs): the instantiations that sit at that boundary
@@ -1748,7 +1773,7 @@ constexpr int kW5VnBlocks = 7;
 template <bool MINSUM, bool WANT_LLR, bool LDS_RESIDENT, int MAXD, int LLR_MODE, bool RATIO>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void decode_kernel_w5(const DecodeArgs a)
 {
-    decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO, false, false, kW5VnBlocks>(a);
+    decode_body<MINSUM, WANT_LLR, LDS_RESIDENT, MAXD, LLR_MODE, RATIO, false, false, kW5VnBlocks>(a, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2125,11 +2150,34 @@ __global__ __launch_bounds__(1024) void batch_counters_kernel(const uint32_t *it
 {
     __shared__ long long part[4][16];
     long long fe = 0, be = 0, it = 0, es = 0;
-    for (uint64_t i = threadIdx.x; i < n; i += 1024)
+    auto take = [&](uint32_t b, uint32_t t) { fe += b > 0, be += b, it += t, es += early_term && t < max_iters; };
+    // four frames per load, four loads in flight per array: the kernel sits between two batches' decode launches, and 64
+    // dependent round trips per thread (one frame per load) were 35 us of every step
+    uint64_t done = 0;
+    if ((reinterpret_cast<uintptr_t>(iters) | reinterpret_cast<uintptr_t>(bit_errors)) % 16 == 0)
     {
-        const uint32_t b = bit_errors[i], t = iters[i];
-        fe += b > 0, be += b, it += t, es += early_term && t < max_iters;
+        const uint4 *b4 = reinterpret_cast<const uint4 *>(bit_errors), *t4 = reinterpret_cast<const uint4 *>(iters);
+        const uint64_t n4 = n / 4;
+        uint64_t i = threadIdx.x;
+        for (; i + 3 * 1024 < n4; i += 4 * 1024)
+        {
+            uint4 b[4], t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                b[k] = b4[i + k * 1024], t[k] = t4[i + k * 1024];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                take(b[k].x, t[k].x), take(b[k].y, t[k].y), take(b[k].z, t[k].z), take(b[k].w, t[k].w);
+        }
+        for (; i < n4; i += 1024)
+        {
+            const uint4 b = b4[i], t = t4[i];
+            take(b.x, t.x), take(b.y, t.y), take(b.z, t.z), take(b.w, t.w);
+        }
+        done = n4 * 4;
     }
+    for (uint64_t i = done + threadIdx.x; i < n; i += 1024)
+        take(bit_errors[i], iters[i]);
     auto wave_total = [](long long v) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1)
@@ -2188,13 +2236,18 @@ template <bool LDS_RESIDENT, int MAXD, int LLR_MODE>
 int launch_decode_impl(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, void *stream)
 {
     const bool want_llr = a.llr_out != nullptr;
+    // LDS-resident: the launch over the first launch's list (ratio_separate, a list coming in, none going out) is the chain
+    // kernel decode_kernel_list; memory-resident: a separately dividing ratio launch with lists on both sides
+    const bool list_chain = LDS_RESIDENT && a.ratio_separate && a.redo_count_in && !a.redo_list;
+    if (list_chain && (min_sum || !a.early_term || a.iterations == 0 || !a.redo_list_in || a.redo_iter_in))
+        return hipErrorInvalidValue;
     const bool ratio = a.redo_list != nullptr;
     // without early termination the ratio form runs with the hand-over to the LLR-domain form (detmath.h "Hand-over")
     const bool handover = ratio && !a.early_term;
     if (ratio && (min_sum || a.iterations == 0 || !a.redo_count || (a.redo_count_in && !a.ratio_separate) ||
                   (handover && (!a.redo_iter || !a.ws_handover))))
         return hipErrorInvalidValue;
-    if (a.ratio_separate && (!ratio || handover || (!LDS_RESIDENT && MAXD < 6)))
+    if (a.ratio_separate && !list_chain && (!ratio || handover || LDS_RESIDENT || MAXD < 6))
         return hipErrorInvalidValue;
     if (a.redo_iter_in && !a.ws_handover)
         return hipErrorInvalidValue;
@@ -2231,8 +2284,8 @@ int launch_decode_impl(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, vo
                 if (few_vn_blocks)
                     k = want_llr ? decode_kernel_handover<true, MAXD, LLR_MODE, kW5VnBlocks> : decode_kernel_handover<false, MAXD, LLR_MODE, kW5VnBlocks>;
         }
-        else if (ratio && a.ratio_separate)
-            k = want_llr ? decode_kernel<false, true, true, MAXD, LLR_MODE, true, true> : decode_kernel<false, false, true, MAXD, LLR_MODE, true, true>;
+        else if (list_chain)
+            k = want_llr ? decode_kernel_list<true, MAXD, LLR_MODE> : decode_kernel_list<false, MAXD, LLR_MODE>;
     }
     if constexpr (!LDS_RESIDENT && MAXD >= 6)
         if (ratio && a.ratio_separate)
@@ -2243,8 +2296,8 @@ int launch_decode_impl(const DecodeArgs &a, bool min_sum, uint32_t lds_bytes, vo
                                        static_cast<int>(lds_bytes));
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(a.n_frames)), dim3(kThreads), lds_bytes,
-                       static_cast<hipStream_t>(stream), a);
+    const unsigned grid = list_chain ? static_cast<unsigned>(std::min<uint64_t>(a.n_frames, 1024)) : static_cast<unsigned>(a.n_frames);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds_bytes, static_cast<hipStream_t>(stream), a);
     return hipGetLastError();
 }
 

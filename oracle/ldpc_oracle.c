@@ -828,8 +828,6 @@ static int dec_decode_ratio(dec_t *d, int allow_shared)
    check node (n >= rho_ch d), degree-2 variable nodes receive rho(c2v) and multiply.  Same schedule as dec_decode_ratio;
    v2c[] holds rho(v2c) (a leaf's edge: its constant rho_ch), c2v[] holds lambda(c2v), or rho(c2v) on edges into variable
    nodes of degree 2 (nothing on a leaf's edge).  Returns the iteration count, or -1 when a value left its range. */
-uint32_t g_pmax;
-uint32_t orc_pmax(int reset) { uint32_t v = g_pmax; if (reset) g_pmax = 0; return v; }
 static int fused_applies(const orc_code *c)
 {
     const spm *H = &c->H;
@@ -863,7 +861,6 @@ static int fused_cn_pass(dec_t *d, const double *rho, int shared, int handover, 
             h = dm_cnf3(v, flip, leaf, shared, &lb, &tot);
         else
             h = dm_cnf4(v, flip, leaf, shared, &lb, &tot);
-        { extern uint32_t g_pmax; if (shared && h > g_pmax) g_pmax = h; }
         escaped |= shared && h >= DM_FUSED_P_HI;
         for (int k = 0; k < cw - leaf; ++k)
             d->c2v[cn[order[k]]] = handover ? 0.0 - dm_log(v[k]) : v[k];

@@ -399,6 +399,36 @@ def test_8k_bulk_bit_exact_vs_det_oracle(dec8k, h8k_file, x, ms, early, iters, n
     assert np.array_equal(r["bit_errors"], be)
 
 
+def _oracle_chunk_stats(args):
+    path, chan, x, seed, skip, count = args
+    orc.ratio_stats(reset=True)
+    o = orc.Code(path).run_frames(chan, x, seed=seed, skip=skip, count=count, math=orc.MATH_DET, want_vectors=False)
+    return o["iters"], o["bit_errors"], orc.ratio_stats(), orc.ratio_second()
+
+
+@pytest.mark.parametrize("x", [9.0, 14.0])
+def test_list_launch_walks_lists_longer_than_its_grid(dec, x):
+    """The LDS-resident decoder's launch over the first launch's list (kernels.hip, decode_kernel_list: at most 1 024
+    workgroups walk it, each frame through the separately dividing form and, if it has to, the LLR domain): 4 096 frames at
+    9 dB, where a part of the batch is handed back and a part of that goes on to the LLR domain, and at 14 dB, where nearly
+    every frame takes all three forms — lists several times as long as the grid.  Every frame's iteration count and
+    bit-error count equal the oracle's, which counts the stages."""
+    import multiprocessing as mp
+    n, parts = 4096, 16
+    per = n // parts
+    with mp.get_context("spawn").Pool(parts) as pool:
+        res = pool.map(_oracle_chunk_stats, [(orc.H_TXT, "AWGN", x, 4, k * per, per) for k in range(parts)])
+    it = np.concatenate([r[0] for r in res])
+    be = np.concatenate([r[1] for r in res])
+    second = sum(r[3] for r in res)
+    escaped = sum(r[2][1] for r in res)
+    assert second > 1024 and (escaped > 1024 if x > 10 else escaped > 0), (second, escaped)  # longer than the grid
+    dec.stream_begin("AWGN", 4, x)
+    r = dec.stream_decode(n, want=("iters", "bit_errors"))
+    assert np.array_equal(r["iters"], it)
+    assert np.array_equal(r["bit_errors"], be)
+
+
 def test_fast_mode_is_opt_in_and_close(dec):
     """SURVEY §8f item 4: the NON-PARITY binary32 mode.  Off by default (everything above ran the binary64 kernels);
     when switched on, the frame-error rate over 131 072 frames of the headline stream stays within 25 % of the

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(kBecThreads) __attribute__((amdgpu_waves_per_eu(6, 
         for (int i = tid; i < P.n_bitpos; i += kBecThreads)
         {
             const uint32_t r = P.tx_rank[i];
-            ew[i] = ran ? (LE[r] & ~X[r]) : 0;
+            ew[i] = ran ? (LE[r] & ~X[r]) : X[r]; // (no iteration ran: every decision is 0, wrong where the bit is 1)
         }
         __syncthreads();
         // thread (part, f): frame f over every 16th position (two parts per wave)

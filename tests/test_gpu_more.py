@@ -68,6 +68,18 @@ def test_bec_defined_semantics_vs_oracle(decg):
         assert np.array_equal(r[k], o[k].astype(r[k].dtype)), k
 
 
+def test_bec_zero_and_few_iterations_with_generator(decg):
+    """Encoded (non-zero) codewords through the erasure decoder with NO iteration (every decision 0: the bit errors are the
+    ones of the codeword) and with one and two (nothing has converged yet): every output equals the oracle's."""
+    code = orc.Code(orc.H_TXT, orc.G_TXT)
+    for iters, early in ((0, True), (1, True), (2, False)):
+        r = _run(decg, ("BEC", "BP", iters, int(early), 7, 0.6, 1, 40), compat=False)
+        o = code.run_frames("BEC", 0.6, seed=7, skip=1, count=40, early_term=early, iters=iters, bec_compat=False)
+        for k in OUT:
+            assert np.array_equal(r[k], o[k].astype(r[k].dtype)), (iters, k)
+    assert r["bit_errors"].min() > 0
+
+
 def test_bec_counters_500_frames(decg, golden_counters):
     decg.set_bec_compat(True)
     decg.stream_begin("BEC", 0, 0.8)

@@ -376,13 +376,32 @@ DM_FN double dm_e_to_llr(uint32_t sign_word, double e)
  * ------------------------------------------------------------------------------------------------ */
 #define DM_SAT_MIN 40.0
 DM_FN int dm_sat_applies(double mu, double amax) { return mu >= DM_SAT_MIN && amax - mu <= DM_SHARED_LIMIT; }
+/*
+ * Later still the differences double too and leave that window (amax - mu > DM_SHARED_LIMIT): a converged frame of the
+ * (3,6) code reaches it around iteration 30 of 50, and the chain of dm_boxplus that was the fall-back costs three times the
+ * saturated form (measured on the n = 8192 code: 0.45 ms per iteration of an 8 192-frame batch in the window, 1.27 ms
+ * beyond it, where a wave's lanes split between the two and the wave pays for both).  The saturated form needs only ONE
+ * more thing there: the output of the edge that HOLDS the minimum mu is the combination of the OTHER inputs, which may all
+ * be far away — their E' = e^-(|v| - mu) underflow — so that one output takes its own base: with jm the first index where
+ * |v| = mu and m2 = min_{i != jm} |v_i|,
+ *
+ *     |c2v_jm| = m2 - log( sum_{i != jm} e^-min(|v_i| - m2, 700) )      (in index order; the sum contains a 1)
+ *
+ * and every other output is the saturated form's, base mu (its sum contains E'_jm = 1; inputs more than 700 above the base
+ * enter as e^-700 instead of less: 64 e^-700 relative, nothing).  Same error analysis as above, no condition on the spread.
+ * Rule (nodes of degree 5..16: below, the chain is three or six box-pluses that mostly take their +-min short cut, cheaper
+ * than this form — measured on h.txt; above 16 the wide-node scratch form keeps the chain): mu >= DM_SAT_MIN and
+ * amax - mu > DM_SHARED_LIMIT -> the saturated form with that one output replaced.
+ */
+DM_FN int dm_sat2_applies(double mu, double amax) { return mu >= DM_SAT_MIN && amax - mu > DM_SHARED_LIMIT; }
 DM_FN double dm_sat_e(double absv, double mu) { return dm_boxplus_exp(absv - mu); }
-DM_FN double dm_sat_llr(uint32_t sign_word, double mu, double sum)
+DM_FN double dm_sat_mag(double mu, double sum) { return mu - dm_boxplus_log(sum); }
+DM_FN double dm_sat_signed(uint32_t sign_word, double mag)
 {
-    double mag = mu - dm_boxplus_log(sum);
     double sd = dm_from_bits((uint64_t)(0x3FF00000u | (sign_word & 0x80000000u)) << 32); /* s as +-1.0 */
     return DM_FMA(sd, mag, 0.0);
 }
+DM_FN double dm_sat_llr(uint32_t sign_word, double mu, double sum) { return dm_sat_signed(sign_word, dm_sat_mag(mu, sum)); }
 
 /* ------------------------------------------------------------------------------------------------
  * Likelihood-ratio form of the whole BP iteration (no exp/log inside the loop).

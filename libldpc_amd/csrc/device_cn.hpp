@@ -55,9 +55,40 @@ __device__ __forceinline__ void cn_core(double (&v)[D])
             amax = __builtin_fmax(amax, __builtin_fabs(v[j]));
             mu = __builtin_fmin(mu, __builtin_fabs(v[j]));
         }
-        if (dm_sat_applies(mu, amax))
+        if (mu >= DM_SAT_MIN && ((D >= 5 && D <= 16) || amax - mu <= DM_SHARED_LIMIT))
         {
+            // the saturated form; where the inputs' spread has left its window (dm_sat2_applies) the output of the (first)
+            // edge that holds the minimum is replaced by its own-base value (detmath.h).  One pass through the form for the
+            // whole wave, the replacement computed only by the lanes that need it; the edge is found by comparison and its
+            // output chosen by a select: no lane-dependent indexing.
+            const bool far = D >= 5 && D <= 16 && dm_sat2_applies(mu, amax);
+            uint32_t min_edge = 0; // bit j: edge j is the (first) one that holds the minimum
+            double own_mag = 0.0;
+            if (far)
+            {
+                double m2 = __builtin_huge_val();
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                {
+                    const double a = __builtin_fabs(v[j]);
+                    const bool is_min = min_edge == 0 && a == mu;
+                    min_edge |= static_cast<uint32_t>(is_min) << j;
+                    m2 = is_min ? m2 : __builtin_fmin(m2, a);
+                }
+                double own = 0.0; // sum over the OTHER edges, base m2, index order
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    own += (min_edge >> j & 1u) ? 0.0 : dm_sat_e(__builtin_fabs(v[j]), m2);
+                own_mag = dm_sat_mag(m2, own);
+            }
             cn_saturated<D>(v, mu);
+            if (far)
+            {
+                // (the replaced output's sign is the regular one's: the product of the other inputs' signs either way)
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    v[j] = (min_edge >> j & 1u) ? dm_sat_signed(DM_SIGN_WORD(v[j]), own_mag) : v[j];
+            }
             return;
         }
         if (amax <= DM_SHARED_LIMIT)

@@ -387,7 +387,8 @@ static int cn_update_det_shared(dec_t *d, const int *cn, int cw)
         amax = fmax(amax, fabs(v[j]));
         mu = fmin(mu, fabs(v[j]));
     }
-    if (dm_sat_applies(mu, amax))
+    const int two_base = cw >= 5 && cw <= 16 && dm_sat2_applies(mu, amax); /* (detmath.h: degrees 5..16) */
+    if (dm_sat_applies(mu, amax) || two_base)
     {
         /* saturated form (detmath.h): sums of e^-(|v| - mu); F[j] = inputs 0..j, B[j] = inputs j..cw-1 */
         double Fs[MAXD], Bs[MAXD];
@@ -406,6 +407,24 @@ static int cn_update_det_shared(dec_t *d, const int *cn, int cw)
         d->c2v[cn[cw - 1]] = dm_sat_llr(sF[cw - 2], mu, Fs[cw - 2]);
         for (int j = 1; j < cw - 1; ++j)
             d->c2v[cn[j]] = dm_sat_llr(sF[j - 1] ^ sB[j + 1], mu, Fs[j - 1] + Bs[j + 1]);
+        if (two_base)
+        {
+            /* the (first) edge that holds the minimum takes its output from base m2 (detmath.h, dm_sat2_applies) */
+            int jm = 0;
+            while (fabs(v[jm]) != mu)
+                ++jm;
+            double m2 = HUGE_VAL, own = 0.0;
+            uint32_t sign_all = 0;
+            for (int j = 0; j < cw; ++j)
+                if (j != jm)
+                    m2 = fmin(m2, fabs(v[j]));
+            for (int j = 0; j < cw; ++j)
+            {
+                own += j == jm ? 0.0 : dm_sat_e(fabs(v[j]), m2);
+                sign_all ^= sv[j];
+            }
+            d->c2v[cn[jm]] = dm_sat_llr(sign_all ^ sv[jm], m2, own);
+        }
         return 1;
     }
     for (int j = 0; j < cw; ++j)

@@ -321,9 +321,11 @@ __device__ __forceinline__ uint32_t cn_update_ratio(double *m, int stride, uint3
         v[j] = __builtin_fabs(x);
     }
     cn_ratio<D, SH == 1, SH == 2>(v, &esc, &esc);
+    // (SH = 2: the range check of this pass may be IGNORED — the frame ends at this pass's vote, detmath.h — so what an
+    // overflowed node wrote must still carry the decisions: a NaN's own sign bit is cleared before the decision goes in)
 #pragma unroll
     for (int j = 0; j < D; ++j)
-        m[j * stride] = with_sign(v[j], sg[j]);
+        m[j * stride] = with_sign(SH == 2 ? __builtin_fabs(v[j]) : v[j], sg[j]);
     return par;
 }
 
@@ -362,10 +364,10 @@ __device__ __forceinline__ uint32_t cn_update_ratio2(double *m0, double *m1, uin
     cn_ratio<D1, SH == 1, SH == 2>(v1, &esc, &esc);
 #pragma unroll
     for (int j = 0; j < D0; ++j)
-        m0[j * kWaveSize] = with_sign(v0[j], g0[j]);
+        m0[j * kWaveSize] = with_sign(SH == 2 ? __builtin_fabs(v0[j]) : v0[j], g0[j]);
 #pragma unroll
     for (int j = 0; j < D1; ++j)
-        m1[j * kWaveSize] = with_sign(v1[j], g1[j]);
+        m1[j * kWaveSize] = with_sign(SH == 2 ? __builtin_fabs(v1[j]) : v1[j], g1[j]);
     return par0 | par1;
 }
 

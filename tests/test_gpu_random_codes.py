@@ -279,6 +279,14 @@ def test_degree6_shared_reciprocals_three_launches(name, vn, cn, residency, form
         assert np.array_equal(hard, r["hard"][f]) and np.array_equal(out, r["llr_out"][f]), (name, f, k)
     done, escaped = orc.ratio_stats()
     assert orc.ratio_second() == kinds.count("odd") + kinds.count("even")  # the first launch gave all crafted frames up
+    # far above the threshold: frames converge in the first pass, and the check-node pass the kernels run beyond it (the
+    # memory-resident one: always; its outputs are never used) overflows the shared reciprocals — ignored by the rule, and the
+    # garbage it writes must not disturb the decisions that ride in the message slots' sign bits
+    d.stream_begin("AWGN", 5, 13.5)
+    r = d.stream_decode(6, want=OUT)
+    o = code.run_frames("AWGN", 13.5, seed=5, count=6, math=orc.MATH_DET)
+    for k in OUT:
+        assert np.array_equal(r[k], o[k].astype(r[k].dtype)), (name, "13.5 dB", k)
     # the third launch took the even ones (in the code with degree-1 variable nodes some odd ones too), the second finished the rest
     assert escaped >= kinds.count("even") and done + escaped == len(kinds) and done > kinds.count("plain")
     assert escaped == kinds.count("even") or name == "registers_messages"

@@ -36,6 +36,17 @@ for t in range(trials):
         for k in OUT:
             if not np.array_equal(r[k], o[k].astype(r[k].dtype)):
                 print("MISMATCH BEC", t, path, compat, eps, n, early, iters, k); sys.exit(1)
+    # other modes on the same code: min-sum (early termination on / off), sum-product with fixed iterations (hand-over), BSC
+    for ch, x, ms, early, iters in (("AWGN", float(rng.choice([1.0, 3.0, 8.0])), True, bool(rng.integers(0, 2)), int(rng.choice([5, 30]))),
+                                    ("AWGN", float(rng.choice([2.0, 5.0, 10.0])), False, False, int(rng.choice([6, 40]))),
+                                    ("BSC", float(rng.choice([0.02, 0.08])), bool(rng.integers(0, 2)), True, 25)):
+        n = int(rng.choice([3, 17]))
+        d.stream_begin(ch, seed, x)
+        r = d.stream_decode(n, early_term=early, iterations=iters, decoding="BP_MS" if ms else "BP", want=OUT)
+        o = code.run_frames(ch, x, seed=seed, count=n, min_sum=ms, early_term=early, iters=iters, math=orc.MATH_DET)
+        for k in OUT:
+            if not np.array_equal(r[k], o[k].astype(r[k].dtype)):
+                print("MISMATCH", ch, t, path, x, ms, early, iters, n, k); sys.exit(1)
     x = float(rng.choice([2.0, 6.0, 9.0, 12.0])); n = int(rng.choice([5, 40]))
     d.stream_begin("AWGN", seed, x)
     r = d.stream_decode(n, want=OUT)

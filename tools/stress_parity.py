@@ -36,6 +36,18 @@ for t in range(trials):
         for k in OUT:
             if not np.array_equal(r[k], o[k].astype(r[k].dtype)):
                 print("MISMATCH BEC", t, path, compat, eps, n, early, iters, k); sys.exit(1)
+    # the erasure channel's stream over several calls of odd sizes (groups of 32 frames start afresh in every call)
+    d.set_bec_compat(False)
+    d.stream_begin("BEC", seed, 0.3)
+    sizes = [int(v) for v in rng.choice([1, 7, 32, 33, 65], size=4)]
+    o = code.run_frames("BEC", 0.3, seed=seed, count=sum(sizes), bec_compat=False)
+    at = 0
+    for n in sizes:
+        r = d.stream_decode(n, want=OUT)
+        for k in OUT:
+            if not np.array_equal(r[k], o[k][at:at + n].astype(r[k].dtype)):
+                print("MISMATCH BEC stream", t, path, sizes, at, k); sys.exit(1)
+        at += n
     # other modes on the same code: min-sum (early termination on / off), sum-product with fixed iterations (hand-over), BSC
     for ch, x, ms, early, iters in (("AWGN", float(rng.choice([1.0, 3.0, 8.0])), True, bool(rng.integers(0, 2)), int(rng.choice([5, 30]))),
                                     ("AWGN", float(rng.choice([2.0, 5.0, 10.0])), False, False, int(rng.choice([6, 40]))),
